@@ -1,0 +1,257 @@
+/*
+ * pn2_oracle.c -- TEST INFRASTRUCTURE ONLY (never linked or called by the product path).
+ *
+ * Scalar C restatement of the index/geometry ops of the reference's PointNet++ hot path,
+ * written so that every fp32 rounding step is explicit and machine independent.
+ * Compile with  gcc -O2 -ffp-contract=off -mfma  (see oracle/Makefile): the only fused
+ * multiply-adds are the explicit fmaf() calls below.
+ *
+ * Parity status: PINNED.  Every function here is checked bit-for-bit (indices, distances,
+ * weights) against the .npz files under tests/golden, which were produced by importing the reference's own
+ * Modules/PointNet2 in the build container (tests/golden/make_golden.py).
+ *
+ * Reference lines restated (paths relative to the reference repo):
+ *   pn2o_square_distance   Modules/PointNet2/pointnet2_utils.py:21-42
+ *   pn2o_fps               Modules/PointNet2/pointnet2_utils.py:66-89
+ *   pn2o_ball_query        Modules/PointNet2/pointnet2_utils.py:92-136
+ *   pn2o_gather            Modules/PointNet2/pointnet2_utils.py:45-63   (index_points)
+ *   pn2o_group             Modules/PointNet2/pointnet2_utils.py:139-167 (sample_and_group body)
+ *   pn2o_three_nn          Modules/PointNet2/blocks.py:194-203
+ *   pn2o_three_interpolate Modules/PointNet2/blocks.py:204
+ *
+ * Numerics contract (measured against the imported reference):
+ *   dot(q,p)        = fma(qz,pz, fma(qy,py, qx*px))        (what MKL sgemm does for K=3)
+ *   |v|^2           = (vx*vx + vy*vy) + vz*vz              (separate mul/add, no fma)
+ *   sqdist(src,dst) = ((-2*dot) + |src|^2) + |dst|^2
+ *   FPS distance    = ((dx*dx + dy*dy) + dz*dz)            (no fma)
+ *   ties: max/argmin take the lowest index, sort is stable.
+ *
+ * All arrays are dense row-major; xyz arrays are [B][N][3] float, indices are int64.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+static inline float dot3_mkl(const float *q, const float *p) {
+    return fmaf(q[2], p[2], fmaf(q[1], p[1], q[0] * p[0]));
+}
+
+static inline float norm2(const float *v) {
+    float a = v[0] * v[0];
+    float b = v[1] * v[1];
+    float c = v[2] * v[2];
+    float ab = a + b;
+    return ab + c;
+}
+
+static inline float sqdist_ref(const float *src, float src_n2, const float *dst, float dst_n2) {
+    float d = -2.0f * dot3_mkl(src, dst);
+    d = d + src_n2;
+    d = d + dst_n2;
+    return d;
+}
+
+/* out[b][n][m] = sqdist(src[b][n], dst[b][m]) */
+void pn2o_square_distance(const float *src, const float *dst, int B, int N, int M, float *out) {
+    for (int b = 0; b < B; ++b) {
+        const float *s = src + (size_t)b * N * 3;
+        const float *d = dst + (size_t)b * M * 3;
+        float *o = out + (size_t)b * N * M;
+        for (int n = 0; n < N; ++n) {
+            float sn = norm2(s + 3 * n);
+            for (int m = 0; m < M; ++m)
+                o[(size_t)n * M + m] = sqdist_ref(s + 3 * n, sn, d + 3 * m, norm2(d + 3 * m));
+        }
+    }
+}
+
+/* Iterative farthest point sampling; start[b] is the reference's torch.randint draw. */
+void pn2o_fps(const float *xyz, int B, int N, int npoint, const int64_t *start, int64_t *out) {
+    float *mind = (float *)malloc(sizeof(float) * (size_t)N);
+    for (int b = 0; b < B; ++b) {
+        const float *p = xyz + (size_t)b * N * 3;
+        for (int n = 0; n < N; ++n) mind[n] = 1e10f;
+        int64_t far = start[b];
+        for (int i = 0; i < npoint; ++i) {
+            out[(size_t)b * npoint + i] = far;
+            const float cx = p[3 * far], cy = p[3 * far + 1], cz = p[3 * far + 2];
+            float best = -1.0f;
+            int64_t besti = 0;
+            for (int n = 0; n < N; ++n) {
+                float dx = p[3 * n] - cx, dy = p[3 * n + 1] - cy, dz = p[3 * n + 2] - cz;
+                float a = dx * dx, bq = dy * dy, c = dz * dz;
+                float ab = a + bq;
+                float d = ab + c;
+                if (d < mind[n]) mind[n] = d;
+                if (mind[n] > best) { best = mind[n]; besti = n; } /* first maximum wins */
+            }
+            far = besti;
+        }
+    }
+    free(mind);
+}
+
+/*
+ * Ball query.  out is [B][S][Keff], Keff = min(K, N).  r2 is float32(double(radius)**2).
+ * A point is inside when NOT (d > r2).
+ */
+void pn2o_ball_query(const float *xyz, const float *new_xyz, int B, int N, int S, float r2, int K,
+                     int64_t *out) {
+    int Keff = K < N ? K : N;
+    float *pn = (float *)malloc(sizeof(float) * (size_t)N);
+    for (int b = 0; b < B; ++b) {
+        const float *p = xyz + (size_t)b * N * 3;
+        const float *q = new_xyz + (size_t)b * S * 3;
+        for (int n = 0; n < N; ++n) pn[n] = norm2(p + 3 * n);
+        for (int s = 0; s < S; ++s) {
+            int64_t *o = out + ((size_t)b * S + s) * Keff;
+            float qn = norm2(q + 3 * s);
+            int cnt = 0;
+            float dmin = INFINITY;
+            int64_t imin = 0;
+            int have_min = 0;
+            for (int n = 0; n < N; ++n) {
+                float d = sqdist_ref(q + 3 * s, qn, p + 3 * n, pn[n]);
+                if (!(d > r2)) {
+                    if (cnt < Keff) o[cnt] = n;
+                    ++cnt;
+                    if (cnt >= Keff) break;
+                }
+                if (!have_min || d < dmin) { dmin = d; imin = n; have_min = 1; }
+            }
+            if (cnt == 0) { /* empty ball: nearest point (argmin, first minimum) fills the row */
+                /* the scan above never broke early, so dmin/imin cover all N */
+                for (int k = 0; k < Keff; ++k) o[k] = imin;
+            } else {
+                for (int k = cnt; k < Keff; ++k) o[k] = o[0];
+            }
+        }
+    }
+    free(pn);
+}
+
+/* out[b][s][c] = points[b][idx[b][s]][c]   (index_points with a flattened index shape) */
+void pn2o_gather(const float *points, const int64_t *idx, int B, int N, int C, int S, float *out) {
+    for (int b = 0; b < B; ++b)
+        for (int s = 0; s < S; ++s) {
+            int64_t j = idx[(size_t)b * S + s];
+            memcpy(out + ((size_t)b * S + s) * C, points + ((size_t)b * N + j) * C, sizeof(float) * (size_t)C);
+        }
+}
+
+/* gradient of pn2o_gather: dpoints[b][idx[b][s]][c] += dout[b][s][c], sequential in s */
+void pn2o_gather_grad(const float *dout, const int64_t *idx, int B, int N, int C, int S, float *dpoints) {
+    memset(dpoints, 0, sizeof(float) * (size_t)B * N * C);
+    for (int b = 0; b < B; ++b)
+        for (int s = 0; s < S; ++s) {
+            int64_t j = idx[(size_t)b * S + s];
+            for (int c = 0; c < C; ++c)
+                dpoints[((size_t)b * N + j) * C + c] += dout[((size_t)b * S + s) * C + c];
+        }
+}
+
+/*
+ * sample_and_group body after FPS/ball query:
+ *   out[b][s][k][0:3]   = xyz[b][idx[b][s][k]] - new_xyz[b][s]
+ *   out[b][s][k][3:3+D] = feats[b][idx[b][s][k]]          (D may be 0)
+ * xyz_last != 0 gives the MSG channel order [feats, xyz_norm] (blocks.py:143-146).
+ */
+void pn2o_group(const float *xyz, const float *new_xyz, const float *feats, const int64_t *idx, int B,
+                int N, int S, int K, int D, int xyz_last, float *out) {
+    int C = 3 + D;
+    for (int b = 0; b < B; ++b)
+        for (int s = 0; s < S; ++s)
+            for (int k = 0; k < K; ++k) {
+                int64_t j = idx[((size_t)b * S + s) * K + k];
+                float *o = out + (((size_t)b * S + s) * K + k) * C;
+                float *ox = xyz_last ? o + D : o;
+                float *of = xyz_last ? o : o + 3;
+                for (int c = 0; c < 3; ++c)
+                    ox[c] = xyz[((size_t)b * N + j) * 3 + c] - new_xyz[((size_t)b * S + s) * 3 + c];
+                for (int c = 0; c < D; ++c) of[c] = feats[((size_t)b * N + j) * D + c];
+            }
+}
+
+/*
+ * three_nn: for every xyz1 point the 3 (or kk = min(3,S)) smallest sqdist(xyz1, xyz2) entries in
+ * stable-sort order (ties -> lower index first).  dist/idx are [B][N][kk].
+ */
+void pn2o_three_nn(const float *xyz1, const float *xyz2, int B, int N, int S, int64_t *idx, float *dist) {
+    int kk = S < 3 ? S : 3;
+    float *n2 = (float *)malloc(sizeof(float) * (size_t)S);
+    for (int b = 0; b < B; ++b) {
+        const float *p1 = xyz1 + (size_t)b * N * 3;
+        const float *p2 = xyz2 + (size_t)b * S * 3;
+        for (int s = 0; s < S; ++s) n2[s] = norm2(p2 + 3 * s);
+        for (int n = 0; n < N; ++n) {
+            float bd[3] = {INFINITY, INFINITY, INFINITY};
+            int64_t bi[3] = {-1, -1, -1};
+            float sn = norm2(p1 + 3 * n);
+            for (int s = 0; s < S; ++s) {
+                float d = sqdist_ref(p1 + 3 * n, sn, p2 + 3 * s, n2[s]);
+                /* strict '<' keeps the earlier index ahead on ties (stable sort order) */
+                if (bi[0] < 0 || d < bd[0]) {
+                    bd[2] = bd[1]; bi[2] = bi[1]; bd[1] = bd[0]; bi[1] = bi[0]; bd[0] = d; bi[0] = s;
+                } else if (bi[1] < 0 || d < bd[1]) {
+                    bd[2] = bd[1]; bi[2] = bi[1]; bd[1] = d; bi[1] = s;
+                } else if (bi[2] < 0 || d < bd[2]) {
+                    bd[2] = d; bi[2] = s;
+                }
+            }
+            for (int k = 0; k < kk; ++k) {
+                idx[((size_t)b * N + n) * kk + k] = bi[k];
+                dist[((size_t)b * N + n) * kk + k] = bd[k];
+            }
+        }
+    }
+    free(n2);
+}
+
+/* w = (1/max(d,1e-6)) / sum_k(1/max(d_k,1e-6)); the 3-term sum is (r0 + r1) + r2 */
+void pn2o_three_weights(const float *dist, size_t rows, float *w) {
+    for (size_t i = 0; i < rows; ++i) {
+        float r[3];
+        for (int k = 0; k < 3; ++k) {
+            float d = dist[3 * i + k];
+            if (d < 1e-6f) d = 1e-6f;
+            r[k] = 1.0f / d;
+        }
+        float s = r[0] + r[1];
+        s = s + r[2];
+        for (int k = 0; k < 3; ++k) w[3 * i + k] = r[k] / s;
+    }
+}
+
+/* out[b][n][c] = (p[i0][c]*w0 + p[i1][c]*w1) + p[i2][c]*w2, separate mul/add */
+void pn2o_three_interpolate(const float *points2, const int64_t *idx, const float *w, int B, int N, int S,
+                            int D, float *out) {
+    for (int b = 0; b < B; ++b)
+        for (int n = 0; n < N; ++n) {
+            const int64_t *ii = idx + ((size_t)b * N + n) * 3;
+            const float *ww = w + ((size_t)b * N + n) * 3;
+            for (int c = 0; c < D; ++c) {
+                float t0 = points2[((size_t)b * S + ii[0]) * D + c] * ww[0];
+                float t1 = points2[((size_t)b * S + ii[1]) * D + c] * ww[1];
+                float t2 = points2[((size_t)b * S + ii[2]) * D + c] * ww[2];
+                float t01 = t0 + t1;
+                out[((size_t)b * N + n) * D + c] = t01 + t2;
+            }
+        }
+}
+
+/* dpoints2[b][idx[b][n][k]][c] += dout[b][n][c] * w[b][n][k]; sequential (n, then k) order */
+void pn2o_three_interpolate_grad(const float *dout, const int64_t *idx, const float *w, int B, int N, int S,
+                                 int D, float *dpoints2) {
+    memset(dpoints2, 0, sizeof(float) * (size_t)B * S * D);
+    for (int b = 0; b < B; ++b)
+        for (int n = 0; n < N; ++n)
+            for (int k = 0; k < 3; ++k) {
+                int64_t j = idx[((size_t)b * N + n) * 3 + k];
+                float wk = w[((size_t)b * N + n) * 3 + k];
+                for (int c = 0; c < D; ++c)
+                    dpoints2[((size_t)b * S + j) * D + c] += dout[((size_t)b * N + n) * D + c] * wk;
+            }
+}
+
+int pn2o_version(void) { return 1; }
