@@ -1,0 +1,161 @@
+"""Headline benchmark: points/sec of PointNet2 forward + loss + backward on a synthetic 262 144-point tree.
+
+    python bench.py [--gpus N --steps K --warmup W] [--depth 4|5] [--points 262144]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = zero grads, PointNet2.forward (SA x4, FP x4, heads), offset-regression loss, backward of 50*loss, one
+gradient all-reduce (N > 1) and the AdamW update -- one pass of the hot path over one batch (one tree per rank:
+weak scaling, no data-path collective).  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE
+JSON line: the contract fields plus `roofline` (dominant libpn2hip kernel, HIP-event timed on its launch stream
+during a second, instrumented run of the same steps) and `cpu_baseline` (oracle/torch_port.py, the torch-CPU
+restatement of the reference path, timed on this box's host cores; rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+from __graft_entry__ import load_pkg  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
+F32_MFMA_PEAK_TFLOPS = 157.3   # dense fp32-input MFMA peak
+
+
+def make_batch(n_points, seed, device):
+    from pn2_amd.synthetic import gaussian_branch_tree
+    xyz, off, _ = gaussian_branch_tree(n_points, seed=seed)
+    return {
+        "coords": torch.from_numpy(xyz.T.copy()[None]).to(device),                  # [1,3,N] raw metres
+        "feats": torch.ones(1, 4, n_points, device=device),                        # the reference's dummy features
+        "masks_pad": torch.ones(1, n_points, dtype=torch.bool, device=device),
+        "masks_off": torch.ones(n_points, dtype=torch.bool, device=device),
+        "semantic_labels": torch.zeros(n_points, dtype=torch.long, device=device),
+        "offset_labels": torch.from_numpy(off).to(device),
+    }
+
+
+def cpu_baseline(depth, n_points, seed):
+    """One full step of the same workload through the torch-CPU restatement of the reference path."""
+    from oracle import torch_port as P
+    batch = {k: v.cpu() for k, v in make_batch(n_points, seed, "cpu").items()}
+    torch.manual_seed(0)
+    model = P.PortPointNet2(depth=depth).train()
+    opt = torch.optim.AdamW(model.parameters(), lr=0.01, weight_decay=1e-3)
+    t0 = time.perf_counter()
+    opt.zero_grad()
+    loss, _, _, _ = P.loss_from_batch(model, batch, mult_sem=0.0)
+    (loss * 50).backward()
+    opt.step()
+    dt = time.perf_counter() - t0
+    return {"value": n_points / dt, "unit": "points/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 step (fwd+loss+bwd+AdamW) of the same depth-{depth} {n_points}-point tree, torch CPU fp32, "
+                      f"{dt:.2f} s, no warm-up"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--depth", type=int, default=4, help="reference layer table (train_PointNet2.py default: 4)")
+    ap.add_argument("--points", type=int, default=262144)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    load_pkg()
+    from pn2_amd import _hip, parallel
+    from pn2_amd.PointNet2.PointNet2 import PointNet2
+
+    rank, local, world = parallel.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    torch.manual_seed(0)                                  # identical random-init weights on every rank
+    model = PointNet2(depth=args.depth, loss_multiplier_semantic=0).to(dev).train()
+    grads = parallel.FlatGradAllReduce(model)
+    opt = torch.optim.AdamW(model.parameters(), lr=0.01, weight_decay=1e-3)   # train_PointNet2.py:250
+    batch = make_batch(args.points, seed=rank, device=dev)
+    torch.manual_seed(1000 + rank)                        # FPS start indices: per-rank stream
+
+    def step():
+        grads.zero()
+        loss, _ = model(batch, return_loss=True)
+        (loss * 50).backward()                            # train_utils.py:57-58
+        grads.allreduce()
+        opt.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t)
+    assert torch.isfinite(loss).item()
+
+    # second, instrumented run of the same steps: HIP events around every libpn2hip launch
+    _hip.timer.reset()
+    _hip.timer.enabled = True
+    for _ in range(args.steps):
+        step()
+    _hip.timer.enabled = False
+    prof = _hip.timer.summary()
+    barrier()
+
+    if rank == 0:
+        kernels = {}
+        for name, d in prof.items():
+            per = d["ms"] / d["calls"]
+            kernels[name] = {"calls_per_step": d["calls"] / args.steps, "ms_per_step": d["ms"] / args.steps,
+                             "avg_launch_us": 1e3 * per,
+                             "algorithmic_GBs": (d["bytes"] / d["calls"]) / (per * 1e-3) / 1e9 if per > 0 else 0.0}
+        dom = max(prof, key=lambda n: prof[n]["ms"])
+        d = prof[dom]
+        # the dominant entry point may be launched at several shapes per step (one per level); the roofline
+        # object is for its largest launch, which carries almost all of its time
+        big = max((r for r in _hip.timer.records if r[0] == dom), key=lambda r: r[3].elapsed_time(r[4]))
+        same = [r for r in _hip.timer.records if r[0] == dom and r[1] == big[1]]
+        avg_ms = sum(r[3].elapsed_time(r[4]) for r in same) / len(same)
+        achieved = big[1] / (avg_ms * 1e-3) / 1e9
+        roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": big[1],
+                    "avg_launch_us": 1e3 * avg_ms, "share_of_step": d["ms"] / args.steps / (1e3 * dt / args.steps)}
+        out = {
+            "metric": "points/sec fwd+bwd, PointNet2 offset-regression, 262k-pt tree, 1/2/4/8 GPUs",
+            "value": args.points * world * args.steps / dt, "unit": "points/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"PointNet2 depth {args.depth} fwd+loss+bwd+AdamW, monolithic B=1 x {args.points}-point "
+                                   f"Gaussian-branch tree per GPU (BASELINE configs[1]), fp32 parity mode",
+                       "points_per_gpu": args.points, "depth": args.depth, "parallelism": f"dp{world} (one tree per rank, "
+                       "1 flat gradient all-reduce per step)"},
+            "roofline": roofline, "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.depth, args.points, seed=0)
+            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,199 @@
+"""PointNet2 model wrapper with the reference's constructor, attribute names, batch-dict keys and return values
+(Modules/PointNet2/PointNet2.py).  This is the caller of the hot path: its forward + loss + backward is the
+unit the benchmark times.
+
+Layer tables per ``depth`` follow reference lines 38-97: SA(npoint, radius, nsample, in_channel, mlp) and
+FP(in_channel, mlp); heads are ConvHead(128 -> 128 -> {2,3}) with BatchNorm1d(eps=1e-4) (lines 22, 103-104).
+"""
+import functools
+
+import torch
+import torch.nn as nn
+
+from ..Loss import point_wise_loss
+from ..Utils import cuda_cast
+from .blocks import (MLP, ConvHead, PointNetFeaturePropagation, PointNetSetAbstraction,
+                     PointNetSetAbstractionMsg)
+
+# depth -> ([SA rows], [FP rows in the order fpN ... fp1]); in_channel of sa1 is filled in at build time
+_SA = {
+    4: [(1024, 0.1, 32, None, [32, 32, 64]), (256, 0.2, 32, 64 + 3, [64, 64, 128]),
+        (64, 0.4, 32, 128 + 3, [128, 128, 256]), (16, 0.8, 32, 256 + 3, [256, 256, 512])],
+    5: [(100, 0.1, 32, None, [32, 32, 64]), (50, 0.2, 32, 64 + 3, [64, 64, 128]),
+        (20, 0.4, 32, 128 + 3, [128, 128, 256]), (8, 0.8, 32, 256 + 3, [256, 256, 512])],
+    6: [None, (100, 0.2, 32, 160 + 3, [64, 64, 128]), (50, 0.4, 32, 128 + 3, [128, 128, 256]),
+        (20, 0.8, 32, 256 + 3, [256, 256, 512])],
+    3: [(1024, 0.1, 32, None, [32, 32, 64]), (256, 0.3, 32, 64 + 3, [64, 64, 128]),
+        (64, 0.6, 32, 128 + 3, [128, 128, 256])],
+    2: [(1024, 0.02, 32, None, [32, 32, 64]), (256, 0.2, 32, 64 + 3, [64, 64, 128])],
+}
+_FP = {
+    4: [(768, [256, 256]), (384, [256, 256]), (320, [256, 128]), (128, [128, 128, 128])],
+    5: [(768, [256, 256]), (384, [256, 256]), (320, [256, 128]), (128, [128, 128, 128])],
+    6: [(768, [256, 256]), (384, [256, 256]), (416, [256, 128]), (128, [128, 128, 128])],
+    3: [(128 + 256, [256, 256]), (64 + 256, [256, 128]), (128, [128, 128, 128])],
+    2: [(64 + 128, [128, 128, 128]), (128, [128, 128, 128])],
+}
+
+
+class PointNet2(nn.Module):
+    def __init__(self, input_nc=3, loss_multiplier_semantic=1, loss_multiplier_offset=1, dim_feat=4,
+                 use_coords=True, use_features=True, depth=4, **kwargs):
+        super().__init__()
+        if depth not in _SA:
+            raise ValueError("Unsupported depth value. Please use depth=2, 3, or 4.")
+        self.loss_multiplier_semantic = loss_multiplier_semantic
+        self.loss_multiplier_offset = loss_multiplier_offset
+        self.use_coords, self.use_features, self.depth = use_coords, use_features, depth
+
+        input_dim = (3 if use_coords else 0) + (dim_feat if use_features else 0)
+        for level, row in enumerate(_SA[depth], start=1):
+            if row is None:  # depth 6: multi-scale first level (reference lines 64-70)
+                sa = PointNetSetAbstractionMsg(npoint=500, radius_list=[0.02, 0.04, 0.08], nsample_list=[16, 32, 32],
+                                               in_channel=input_dim,
+                                               mlp_list=[[16, 16, 32], [32, 32, 64], [64, 64, 64]])
+            else:
+                npoint, radius, nsample, cin, widths = row
+                sa = PointNetSetAbstraction(npoint, radius, nsample, input_dim if cin is None else cin, widths, False)
+            setattr(self, f"sa{level}", sa)
+        n_levels = len(_SA[depth])
+        for k, (cin, widths) in enumerate(_FP[depth]):
+            setattr(self, f"fp{n_levels - k}", PointNetFeaturePropagation(cin, widths))
+
+        norm_fn = functools.partial(nn.BatchNorm1d, eps=1e-4, momentum=0.1)
+        self.semantic_linear = ConvHead(128, 2, norm_fn=norm_fn, num_layers=2)
+        self.offset_linear = ConvHead(128, 3, norm_fn=norm_fn, num_layers=2)
+        self.init_weights()
+
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.BatchNorm1d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+            elif isinstance(m, MLP):
+                m.init_weights()
+
+    # ------------------------------------------------------------------------------------------ flattened mode
+    def forward(self, batch, return_loss):
+        """batch: coords [B,3,N], feats [B,F,N] (+ masks/labels when return_loss).  Reference lines 118-134."""
+        output = dict()
+        output["backbone_feats"] = self.forward_backbone(coords=batch["coords"], feats=batch["feats"])
+        output["semantic_prediction_logits"] = self.semantic_linear(output["backbone_feats"])
+        output["offset_predictions"] = self.offset_linear(output["backbone_feats"])
+        if return_loss:
+            output = self.get_loss(model_output=output, **batch)
+        return output
+
+    @cuda_cast
+    def forward_backbone(self, coords, feats, **kwargs):
+        """SA x L then FP x L; always fp32 (the reference disables autocast here, lines 136-178)."""
+        n = len(_SA[self.depth])
+        with torch.amp.autocast("cuda", enabled=False):
+            xyz = [coords]
+            pts = [feats if self.use_features else None]
+            for level in range(1, n + 1):
+                nx, npts = getattr(self, f"sa{level}")(xyz[-1], pts[-1])
+                xyz.append(nx)
+                pts.append(npts)
+            for level in range(n, 1, -1):
+                pts[level - 1] = getattr(self, f"fp{level}")(xyz[level - 1], xyz[level], pts[level - 1], pts[level])
+            return self.fp1(xyz[0], xyz[1], None, pts[1])
+
+    @staticmethod
+    def _valid_rows(sem_logits, off_preds, masks_pad, masks_off):
+        """[B,C,N] predictions -> rows of real points; the offset rows are additionally filtered by masks_off."""
+        sem = sem_logits.permute(0, 2, 1).reshape(-1, 2)
+        off = off_preds.permute(0, 2, 1).reshape(-1, 3)
+        keep = masks_pad.reshape(-1)
+        return sem[keep], off[keep][masks_off]
+
+    def get_loss(self, model_output, semantic_labels, offset_labels, masks_off, masks_pad, **kwargs):
+        sem, off = self._valid_rows(model_output["semantic_prediction_logits"], model_output["offset_predictions"],
+                                    masks_pad, masks_off)
+        return self.get_loss_hierarchical({"semantic_prediction_logits": sem, "offset_predictions": off},
+                                          semantic_labels, offset_labels)
+
+    def get_loss_hierarchical(self, model_output, semantic_labels, offset_labels, **kwargs):
+        semantic_loss, offset_loss = point_wise_loss(model_output["semantic_prediction_logits"].float(),
+                                                     model_output["offset_predictions"].float(),
+                                                     semantic_labels, offset_labels)
+        loss_dict = {"semantic_loss": semantic_loss * self.loss_multiplier_semantic,
+                     "offset_loss": offset_loss * self.loss_multiplier_offset}
+        return sum(loss_dict.values()), loss_dict
+
+    # --------------------------------------------------------------------------------------- hierarchical modes
+    def _predict_minibatch(self, mini_batch):
+        """Backbone + heads (autocast off, reference line 251) on one padded mini-batch of rasters; returns the
+        valid semantic rows, the valid+masked offset rows and the global point ids of both."""
+        feats = self.forward_backbone(coords=mini_batch["coords"], feats=mini_batch["feats"])
+        with torch.amp.autocast("cuda", enabled=False):
+            sem_logits = self.semantic_linear(feats)
+            off_preds = self.offset_linear(feats)
+        sem, off = self._valid_rows(sem_logits, off_preds, mini_batch["masks_pad"], mini_batch["masks_off"])
+        ids = mini_batch["point_ids"]
+        return sem, off, ids, ids[mini_batch["masks_off"]]
+
+    @staticmethod
+    def _accumulators(n, device):
+        z = functools.partial(torch.zeros, dtype=torch.float, device=device)
+        return z((n, 2)), z((n, 3)), z((n, 1)), z((n, 1))
+
+    @staticmethod
+    def _average(total, count):
+        seen = count.squeeze(1) > 0
+        total[seen] /= count[seen]
+        return total
+
+    def forward_hierarchical_streaming(self, batch, return_loss, scaler=None):
+        """One tree given as a stream of raster mini-batches (reference lines 210-327).  Predictions of
+        overlapping rasters are scatter-averaged per original point id; with ``return_loss`` every mini-batch's
+        loss is back-propagated immediately (scaled by 50 through ``scaler``) so gradients accumulate over the
+        tree.  Returns (avg_loss, loss_dict) when return_loss else the averaged prediction dict."""
+        device = "cuda"
+        sem_sum, off_sum, sem_cnt, off_cnt = self._accumulators(batch["cloud_length"], device)
+        total_loss, n_mb = 0.0, 0
+        loss_dict = {"offset_loss": 0, "semantic_loss": 0}
+        for mini_batch in batch["mini_batches"]:
+            sem, off, ids, ids_off = self._predict_minibatch(mini_batch)
+            sem_sum[ids] += sem.detach()
+            off_sum[ids_off] += off.detach()
+            sem_cnt[ids] += 1
+            off_cnt[ids_off] += 1
+            if return_loss:
+                sem_lab = batch["semantic_labels"].squeeze()[ids.cpu()].to(device)
+                off_lab = batch["offset_labels"][ids_off.cpu()].to(device)
+                mini_loss, mini_dict = self.get_loss_hierarchical(
+                    {"semantic_prediction_logits": sem, "offset_predictions": off}, sem_lab, off_lab, n_points=None)
+                if scaler:
+                    scaler.scale(mini_loss * 50).backward()
+                loss_dict["offset_loss"] += mini_dict["offset_loss"]
+                loss_dict["semantic_loss"] += mini_dict["semantic_loss"]
+                total_loss += mini_loss.item()
+                n_mb += 1
+            del sem, off, mini_batch
+        output = {"semantic_prediction_logits": self._average(sem_sum, sem_cnt),
+                  "offset_predictions": self._average(off_sum, off_cnt)}
+        if not return_loss:
+            return output
+        if n_mb > 0:
+            loss_dict["offset_loss"] /= n_mb
+            loss_dict["semantic_loss"] /= n_mb
+            return total_loss / n_mb, loss_dict
+        # the reference divides by 0.0 here (lines 321-322); an empty stream is reported as zero loss instead
+        return 0.0, loss_dict
+
+    def forward_hierarchical(self, batch, return_loss):
+        """Non-streaming variant (reference lines 329-394): accumulate WITH autograd history, average, then
+        compute one loss on the averaged predictions."""
+        sem_sum, off_sum, sem_cnt, off_cnt = self._accumulators(batch["cloud_length"], "cuda")
+        for mini_batch in batch["mini_batches"]:
+            sem, off, ids, ids_off = self._predict_minibatch(mini_batch)
+            sem_sum[ids] += sem
+            off_sum[ids_off] += off
+            sem_cnt[ids] += 1
+            off_cnt[ids_off] += 1
+        output = {"semantic_prediction_logits": self._average(sem_sum, sem_cnt),
+                  "offset_predictions": self._average(off_sum, off_cnt)}
+        if return_loss:
+            output = self.get_loss_hierarchical(output, batch["semantic_labels"].squeeze(), batch["offset_labels"])
+        return output

@@ -1,0 +1,124 @@
+"""ctypes binding of libpn2hip.so (C ABI: include/pn2_hip.h).
+
+The library is loaded on first use and the import fails LOUDLY when it is missing: there is no CPU fallback
+and nothing here ever routes through oracle/.  Tensors only provide device memory and the stream.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpn2hip.so")
+
+_vp = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_int = ctypes.c_int
+_f32 = ctypes.c_float
+_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/pn2_hip.h declares (tests/test_abi.py checks)
+SIGNATURES = {
+    "pn2_version": (_int, []),
+    "pn2_arch": (ctypes.c_char_p, []),
+    "pn2_square_distance_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _int, _int, _int, _vp, _vp]),
+    "pn2_fps_workspace_bytes": (_sz, [_int, _int, _int]),
+    "pn2_fps_f32": (_int, [_vp, _i64, _i64, _i64, _int, _int, _int, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pn2_ball_query_workspace_bytes": (_sz, [_int, _int, _int, _int]),
+    "pn2_ball_query_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _int, _int, _int, _f32, _int, _vp, _vp,
+                                  _sz, _vp]),
+    "pn2_group_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _int, _int, _int, _int, _int, _int,
+                             _vp, _vp]),
+    "pn2_group_grad_f32": (_int, [_vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _vp]),
+    "pn2_gather_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _int, _int, _int, _int, _vp, _vp]),
+    "pn2_gather_grad_f32": (_int, [_vp, _vp, _int, _int, _int, _int, _vp, _vp]),
+    "pn2_three_nn_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _int, _int, _int, _vp, _vp, _vp, _vp]),
+    "pn2_three_interpolate_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _int, _int, _int, _int, _vp, _i64, _i64, _vp]),
+    "pn2_three_interpolate_grad_f32": (_int, [_vp, _i64, _i64, _vp, _vp, _int, _int, _int, _int, _vp, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the bound library; raises if the HIP extension was not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python build.py` (hipcc --offload-arch=gfx950). "
+                "pn2_amd has no CPU fallback.")
+        cdll = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(cdll, name)  # AttributeError if the symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        if cdll.pn2_version() != 1:
+            raise RuntimeError(f"libpn2hip ABI {cdll.pn2_version()} != 1")
+        _lib = cdll
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        kind = "bad arguments" if status == -1 else "workspace too small" if status == -2 else f"hipError {status}"
+        raise RuntimeError(f"libpn2hip: {what} failed ({kind})")
+
+
+def require_device(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("pn2_amd ops run on a HIP device only (no CPU fallback); got a CPU tensor")
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def f32(t):
+    return t if t.dtype == torch.float32 else t.float()
+
+
+class KernelTimer:
+    """Optional per-entry-point timing with HIP events on the launch stream (used by bench.py for the roofline
+    object; off by default and then costs one attribute test per call)."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = []          # (name, algorithmic_bytes, flops, start_event, end_event)
+
+    def reset(self):
+        self.records = []
+
+    def summary(self):
+        """name -> dict(calls, ms, bytes, flops); synchronises."""
+        torch.cuda.synchronize()
+        out = {}
+        for name, nbytes, flops, e0, e1 in self.records:
+            d = out.setdefault(name, {"calls": 0, "ms": 0.0, "bytes": 0, "flops": 0})
+            d["calls"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["bytes"] += nbytes
+            d["flops"] += flops
+        return out
+
+
+timer = KernelTimer()
+
+
+def call(name, fn, *args, nbytes=0, flops=0):
+    """Invoke one C-ABI entry point and raise on a non-zero status; `nbytes`/`flops` are the ALGORITHMIC traffic
+    and work of this launch, recorded only when the timer is on."""
+    if timer.enabled:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        status = fn(*args)
+        e1.record()
+        timer.records.append((name, int(nbytes), int(flops), e0, e1))
+    else:
+        status = fn(*args)
+    check(status, name)

@@ -1,0 +1,234 @@
+// query_ball_point for gfx950 -- replaces Modules/PointNet2/pointnet2_utils.py:92-136.
+//
+// The reference materialises a [B,S,N] distance matrix, masks it and sorts S*N int64 keys to obtain "the first
+// nsample indices, ascending, with d <= r^2".  Here one wavefront owns Q queries and walks the cloud in index
+// order, 64 points per step: every lane holds one point (coalesced 4-byte loads per coordinate plane), tests
+// it against the Q queries with the reference's exact fp32 expression, and the hits are appended in index
+// order with a wavefront ballot + prefix popcount -- no sort, no distance matrix, early exit once all Q
+// queries hold nsample hits.  When there are few queries the index range is cut into segments scanned by
+// different wavefronts and a small second kernel stitches the per-segment lists back together in order.
+//
+// Empty balls (only possible when the query is not a member of the cloud) take the row argmin, first minimum,
+// like torch.argmin (lines 113-122); short rows are padded with their first hit (lines 126-130).
+#include "pn2_common.h"
+
+namespace {
+
+using u64 = unsigned long long;
+constexpr int kBlock = 256;  // 4 wavefronts
+constexpr int kMaxSeg = 64;
+
+struct Cloud {
+    const float* p;
+    int64_t sn, sc;
+    __device__ __forceinline__ void load(int n, float& x, float& y, float& z) const {
+        const float* q = p + (int64_t)n * sn;
+        x = q[0];
+        y = q[sc];
+        z = q[2 * sc];
+    }
+};
+
+// argmin over the whole cloud for one query, first minimum wins; executed by a full wavefront.
+__device__ int wave_argmin(const Cloud& c, int N, float qx, float qy, float qz, float qn) {
+    const int lane = threadIdx.x & 63;
+    float bd = __builtin_inff();
+    int bi = 0x7FFFFFFF;
+    for (int n = lane; n < N; n += 64) {
+        float x, y, z;
+        c.load(n, x, y, z);
+        const float d = pn2::sqdist(qx, qy, qz, qn, x, y, z, pn2::norm2(x, y, z));
+        if (d < bd) {
+            bd = d;
+            bi = n;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float od = __shfl_xor(bd, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        if (od < bd || (od == bd && oi < bi)) {
+            bd = od;
+            bi = oi;
+        }
+    }
+    return bi == 0x7FFFFFFF ? 0 : bi;
+}
+
+// pad a finished row: lanes k in [cnt, Keff) copy the first hit; cnt == 0 -> argmin fallback
+__device__ void finish_row(const Cloud& c, int N, int32_t* row, int cnt, int first, int Keff, float qx, float qy,
+                           float qz, float qn) {
+    const int lane = threadIdx.x & 63;
+    if (cnt == 0) first = wave_argmin(c, N, qx, qy, qz, qn);
+    for (int k = cnt + lane; k < Keff; k += 64) row[k] = first;
+}
+
+template <int Q>
+__global__ __launch_bounds__(kBlock) void ball_query_kernel(const float* __restrict__ xyz, int64_t sb, int64_t sn,
+                                                            int64_t sc, const float* __restrict__ new_xyz, int64_t qb,
+                                                            int64_t qs, int64_t qc, int B, int N, int S, float r2,
+                                                            int Keff, int32_t* __restrict__ out_idx, int seg_len,
+                                                            int nseg, int32_t* __restrict__ part_idx,
+                                                            int32_t* __restrict__ part_cnt) {
+    const int lane = threadIdx.x & 63;
+    const int nqg = (S + Q - 1) / Q;
+    // wave order [b][seg][query group]: the 4 waves of a workgroup scan the same segment
+    long long w = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    w = __builtin_amdgcn_readfirstlane((int)w);
+    const long long total = (long long)B * nseg * nqg;
+    if (w >= total) return;
+    const int qg = (int)(w % nqg);
+    const int seg = (int)((w / nqg) % nseg);
+    const int b = (int)(w / ((long long)nqg * nseg));
+
+    const Cloud c{xyz + (int64_t)b * sb, sn, sc};
+    float qx[Q], qy[Q], qz[Q], qn[Q];
+    int cnt[Q], first[Q];
+    int32_t* row[Q];
+#pragma unroll
+    for (int i = 0; i < Q; ++i) {
+        const int s = qg * Q + i;
+        const bool ok = s < S;
+        const float* q = new_xyz + (int64_t)b * qb + (int64_t)(ok ? s : 0) * qs;
+        qx[i] = q[0];
+        qy[i] = q[qc];
+        qz[i] = q[2 * qc];
+        qn[i] = pn2::norm2(qx[i], qy[i], qz[i]);
+        cnt[i] = ok ? 0 : Keff;  // a slot beyond S is born full
+        first[i] = 0;
+        const size_t qid = (size_t)b * S + (ok ? s : 0);
+        row[i] = nseg == 1 ? out_idx + qid * Keff : part_idx + (qid * nseg + seg) * Keff;
+    }
+
+    const int n_begin = seg * seg_len;
+    const int n_end = (n_begin + seg_len) < N ? (n_begin + seg_len) : N;
+    const u64 lt = pn2::lanemask_lt();
+    for (int n0 = n_begin; n0 < n_end; n0 += 64) {
+        const int n = n0 + lane;
+        const bool ok = n < n_end;
+        float x, y, z;
+        c.load(ok ? n : n_begin, x, y, z);
+        const float pn = pn2::norm2(x, y, z);
+        bool all_full = true;
+#pragma unroll
+        for (int i = 0; i < Q; ++i) {
+            if (cnt[i] < Keff) {
+                const float d = pn2::sqdist(qx[i], qy[i], qz[i], qn[i], x, y, z, pn);
+                const bool in = ok && !(d > r2);
+                const u64 m = __ballot(in);
+                if (m) {
+                    if (cnt[i] == 0) first[i] = n0 + __builtin_ctzll(m);
+                    const int pos = cnt[i] + __popcll(m & lt);
+                    if (in && pos < Keff) row[i][pos] = n;
+                    cnt[i] += __popcll(m);
+                }
+                all_full = all_full && (cnt[i] >= Keff);
+            }
+        }
+        if (all_full) break;
+    }
+
+#pragma unroll
+    for (int i = 0; i < Q; ++i) {
+        const int s = qg * Q + i;
+        if (s >= S) continue;
+        const int have = cnt[i] < Keff ? cnt[i] : Keff;
+        if (nseg == 1) {
+            finish_row(c, N, row[i], have, first[i], Keff, qx[i], qy[i], qz[i], qn[i]);
+        } else if (lane == 0) {
+            part_cnt[((size_t)b * S + s) * nseg + seg] = have;
+        }
+    }
+}
+
+// One wavefront per query: concatenate the per-segment hit lists in segment (= index) order.
+__global__ __launch_bounds__(kBlock) void ball_query_merge_kernel(const float* __restrict__ xyz, int64_t sb, int64_t sn,
+                                                                  int64_t sc, const float* __restrict__ new_xyz,
+                                                                  int64_t qb, int64_t qs, int64_t qc, int B, int N,
+                                                                  int S, int Keff, int32_t* __restrict__ out_idx,
+                                                                  int nseg, const int32_t* __restrict__ part_idx,
+                                                                  const int32_t* __restrict__ part_cnt) {
+    const int lane = threadIdx.x & 63;
+    long long w = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    w = __builtin_amdgcn_readfirstlane((int)w);
+    if (w >= (long long)B * S) return;
+    const int b = (int)(w / S), s = (int)(w % S);
+    const size_t qid = (size_t)w;
+    int32_t* row = out_idx + qid * Keff;
+    int total = 0, first = 0;
+    for (int seg = 0; seg < nseg && total < Keff; ++seg) {
+        const int c = part_cnt[qid * nseg + seg];
+        const int32_t* src = part_idx + (qid * nseg + seg) * Keff;
+        if (total == 0 && c > 0) first = src[0];
+        for (int j = lane; j < c && total + j < Keff; j += 64) row[total + j] = src[j];
+        total += c;
+    }
+    total = total < Keff ? total : Keff;
+    const float* q = new_xyz + (int64_t)b * qb + (int64_t)s * qs;
+    const float qx = q[0], qy = q[qc], qz = q[2 * qc];
+    const Cloud c{xyz + (int64_t)b * sb, sn, sc};
+    finish_row(c, N, row, total, first, Keff, qx, qy, qz, pn2::norm2(qx, qy, qz));
+}
+
+struct Plan {
+    int Q, nseg, seg_len;
+};
+
+Plan plan(int B, int N, int S) {
+    const long long queries = (long long)B * S;
+    int Q = 8;
+    while (Q > 1 && queries / Q < 4096) Q >>= 1;
+    const long long waves = (queries + Q - 1) / Q;
+    long long nseg = 8192 / (waves > 0 ? waves : 1);
+    const int nblk = pn2::ceil_div(N, 64);
+    if (nseg > kMaxSeg) nseg = kMaxSeg;
+    if (nseg > nblk / 8) nseg = nblk / 8;  // at least 512 points per segment
+    if (nseg < 1) nseg = 1;
+    int seg_len = pn2::ceil_div(pn2::ceil_div(N, nseg), 64) * 64;
+    nseg = pn2::ceil_div(N, seg_len);
+    return Plan{Q, (int)nseg, seg_len};
+}
+
+}  // namespace
+
+extern "C" size_t pn2_ball_query_workspace_bytes(int B, int N, int S, int nsample) {
+    if (B <= 0 || N <= 0 || S <= 0 || nsample <= 0) return 0;
+    const Plan p = plan(B, N, S);
+    const int Keff = nsample < N ? nsample : N;
+    if (p.nseg == 1) return 16;
+    return (size_t)B * S * p.nseg * (Keff + 1) * sizeof(int32_t) + 16;
+}
+
+extern "C" int pn2_ball_query_f32(const float* xyz, int64_t sb, int64_t sn, int64_t sc, const float* new_xyz,
+                                  int64_t qb, int64_t qn, int64_t qc, int B, int N, int S, float r2, int nsample,
+                                  int32_t* out_idx, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!xyz || !new_xyz || !out_idx || B <= 0 || N <= 0 || S <= 0 || nsample <= 0) return PN2_E_BADARG;
+    const Plan p = plan(B, N, S);
+    const int Keff = nsample < N ? nsample : N;
+    if (workspace_bytes < pn2_ball_query_workspace_bytes(B, N, S, nsample) || (p.nseg > 1 && !workspace))
+        return PN2_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    int32_t* part_idx = (int32_t*)workspace;
+    int32_t* part_cnt = part_idx ? part_idx + (size_t)B * S * p.nseg * Keff : nullptr;
+    const int nqg = pn2::ceil_div(S, p.Q);
+    const long long waves = (long long)B * p.nseg * nqg;
+    if (waves > 0x7FFFFFFFll) return PN2_E_BADARG;
+    const dim3 grid((unsigned)((waves + 3) / 4)), block(kBlock);
+#define PN2_BQ_CASE(Q_)                                                                                          \
+    if (p.Q == Q_)                                                                                               \
+        hipLaunchKernelGGL((ball_query_kernel<Q_>), grid, block, 0, s, xyz, sb, sn, sc, new_xyz, qb, qn, qc, B, N, \
+                           S, r2, Keff, out_idx, p.seg_len, p.nseg, part_idx, part_cnt);
+    PN2_BQ_CASE(1)
+    PN2_BQ_CASE(2)
+    PN2_BQ_CASE(4)
+    PN2_BQ_CASE(8)
+#undef PN2_BQ_CASE
+    PN2_LAUNCH_CHECK();
+    if (p.nseg > 1) {
+        const long long q = (long long)B * S;
+        hipLaunchKernelGGL(ball_query_merge_kernel, dim3((unsigned)((q + 3) / 4)), block, 0, s, xyz, sb, sn, sc, new_xyz,
+                           qb, qn, qc, B, N, S, Keff, out_idx, p.nseg, part_idx, part_cnt);
+        PN2_LAUNCH_CHECK();
+    }
+    return 0;
+}

@@ -1,0 +1,124 @@
+// group_points / index_points for gfx950 -- replaces Modules/PointNet2/pointnet2_utils.py:45-63 and the
+// gather + centring + concat of sample_and_group (lines 156-161; MSG variant blocks.py:141-146).
+//
+// Pure data movement: one thread per output element, consecutive threads write consecutive channels of one
+// grouped row, so stores are fully coalesced and the gathered source row (channels-last) is read in
+// contiguous runs.  The backward is a float atomic scatter-add (order differs from the reference's sequential
+// index_put_, so gradients agree to rounding, not bitwise).
+#include "pn2_common.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+__global__ __launch_bounds__(kBlock) void group_kernel(const float* __restrict__ xyz, int64_t sb, int64_t sn, int64_t sc,
+                                                       const float* __restrict__ new_xyz, const float* __restrict__ feats,
+                                                       int64_t fb, int64_t fn, int64_t fc, const int32_t* __restrict__ idx,
+                                                       int B, int N, int S, int K, int D, int xyz_last,
+                                                       float* __restrict__ out, long long total) {
+    const int C = 3 + D;
+    for (long long e = (long long)blockIdx.x * kBlock + threadIdx.x; e < total; e += (long long)gridDim.x * kBlock) {
+        const long long r = e / C;  // (b, s, k)
+        const int c = (int)(e - r * C);
+        const long long bs = r / K;
+        const int b = (int)(bs / S);
+        const int j = idx[r];
+        const int cx = xyz_last ? c - D : c;  // coordinate channel if in [0,3)
+        float v;
+        if (cx >= 0 && cx < 3) {
+            v = __fsub_rn(xyz[(int64_t)b * sb + (int64_t)j * sn + cx * sc], new_xyz[bs * 3 + cx]);
+        } else {
+            const int cf = xyz_last ? c : c - 3;
+            v = feats[(int64_t)b * fb + (int64_t)j * fn + cf * fc];
+        }
+        out[e] = v;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void group_grad_kernel(const float* __restrict__ dout, const int32_t* __restrict__ idx,
+                                                            int B, int N, int S, int K, int D, int xyz_last,
+                                                            float* __restrict__ dfeats, long long total) {
+    const int C = 3 + D;
+    for (long long e = (long long)blockIdx.x * kBlock + threadIdx.x; e < total; e += (long long)gridDim.x * kBlock) {
+        const long long r = e / D;
+        const int cf = (int)(e - r * D);
+        const int b = (int)(r / ((long long)S * K));
+        const int j = idx[r];
+        const float g = dout[r * C + (xyz_last ? cf : cf + 3)];
+        atomicAdd(dfeats + ((int64_t)b * N + j) * D + cf, g);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void gather_kernel(const float* __restrict__ points, int64_t pb, int64_t pn, int64_t pc,
+                                                        const int32_t* __restrict__ idx, int B, int N, int S, int C,
+                                                        float* __restrict__ out, long long total) {
+    for (long long e = (long long)blockIdx.x * kBlock + threadIdx.x; e < total; e += (long long)gridDim.x * kBlock) {
+        const long long r = e / C;
+        const int c = (int)(e - r * C);
+        const int b = (int)(r / S);
+        out[e] = points[(int64_t)b * pb + (int64_t)idx[r] * pn + c * pc];
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void gather_grad_kernel(const float* __restrict__ dout, const int32_t* __restrict__ idx,
+                                                             int B, int N, int S, int C, float* __restrict__ dpoints,
+                                                             long long total) {
+    for (long long e = (long long)blockIdx.x * kBlock + threadIdx.x; e < total; e += (long long)gridDim.x * kBlock) {
+        const long long r = e / C;
+        const int c = (int)(e - r * C);
+        const int b = (int)(r / S);
+        atomicAdd(dpoints + ((int64_t)b * N + idx[r]) * C + c, dout[e]);
+    }
+}
+
+inline unsigned grid_for(long long total) {
+    long long g = (total + kBlock - 1) / kBlock;
+    return (unsigned)(g < 1 ? 1 : (g > 256 * 16 ? 256 * 16 : g));
+}
+
+}  // namespace
+
+extern "C" int pn2_group_f32(const float* xyz, int64_t sb, int64_t sn, int64_t sc, const float* new_xyz,
+                             const float* feats, int64_t fb, int64_t fn, int64_t fc, const int32_t* idx, int B, int N,
+                             int S, int K, int D, int xyz_last, float* out, void* stream) {
+    if (!xyz || !new_xyz || !idx || !out || B <= 0 || N <= 0 || S <= 0 || K <= 0 || D < 0 || (D > 0 && !feats))
+        return PN2_E_BADARG;
+    const long long total = (long long)B * S * K * (3 + D);
+    hipLaunchKernelGGL(group_kernel, dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream, xyz, sb, sn, sc, new_xyz,
+                       feats, fb, fn, fc, idx, B, N, S, K, D, xyz_last, out, total);
+    PN2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pn2_group_grad_f32(const float* dout, const int32_t* idx, int B, int N, int S, int K, int D,
+                                  int xyz_last, float* dfeats, void* stream) {
+    if (!dout || !idx || !dfeats || B <= 0 || N <= 0 || S <= 0 || K <= 0 || D <= 0) return PN2_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    PN2_HIP_CHECK(hipMemsetAsync(dfeats, 0, (size_t)B * N * D * sizeof(float), s));
+    const long long total = (long long)B * S * K * D;
+    hipLaunchKernelGGL(group_grad_kernel, dim3(grid_for(total)), dim3(kBlock), 0, s, dout, idx, B, N, S, K, D, xyz_last,
+                       dfeats, total);
+    PN2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pn2_gather_f32(const float* points, int64_t pb, int64_t pn, int64_t pc, const int32_t* idx, int B,
+                              int N, int S, int C, float* out, void* stream) {
+    if (!points || !idx || !out || B <= 0 || N <= 0 || S <= 0 || C <= 0) return PN2_E_BADARG;
+    const long long total = (long long)B * S * C;
+    hipLaunchKernelGGL(gather_kernel, dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream, points, pb, pn, pc, idx,
+                       B, N, S, C, out, total);
+    PN2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pn2_gather_grad_f32(const float* dout, const int32_t* idx, int B, int N, int S, int C, float* dpoints,
+                                   void* stream) {
+    if (!dout || !idx || !dpoints || B <= 0 || N <= 0 || S <= 0 || C <= 0) return PN2_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    PN2_HIP_CHECK(hipMemsetAsync(dpoints, 0, (size_t)B * N * C * sizeof(float), s));
+    const long long total = (long long)B * S * C;
+    hipLaunchKernelGGL(gather_grad_kernel, dim3(grid_for(total)), dim3(kBlock), 0, s, dout, idx, B, N, S, C, dpoints, total);
+    PN2_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,78 @@
+"""Data-parallel wiring for the hot path: one process per GPU, one gradient all-reduce per optimizer step.
+
+The reference is single-process (no DDP, no collective anywhere); the path shards on the
+batch dimension (trees, or raster mini-batches of one tree) with per-replica BatchNorm statistics, so the only
+exchange is the sum of the flat fp32 gradient (983 845 parameters = 3.94 MB at depth 4/5).  xGMI is
+point-to-point and the buffer is tiny, so it is sent as ONE RCCL all-reduce per step -- in streaming mode the
+model runs ~40 backward passes per step, which is why this is not torch's per-bucket DDP hook: gradients simply
+accumulate locally until ``allreduce_gradients`` is called between the last backward and the optimizer step
+(the place of reference train_utils.py:57-61).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """torchrun-style rendezvous (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).
+    Returns (rank, local_rank, world_size); a plain single process needs none of the variables."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+class FlatGradAllReduce:
+    """Owns one contiguous fp32 buffer that every parameter's ``.grad`` is a view of, so the per-step
+    exchange is a single collective with no packing copies."""
+
+    def __init__(self, module):
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        total = sum(p.numel() for p in self.params)
+        dev = self.params[0].device
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:
+            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero(self):
+        """Replaces optimizer.zero_grad(): keeps the views alive (set_to_none would drop them)."""
+        self.flat.zero_()
+        for p in self.params:
+            if p.grad is None or p.grad.data_ptr() < self.flat.data_ptr():
+                raise RuntimeError("a parameter lost its flat gradient view (zero_grad(set_to_none=True)?)")
+
+    def allreduce(self, average=True):
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            if average:
+                self.flat.div_(dist.get_world_size())
+        return self.flat
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous shard [lo, hi) of n_items for this rank (sizes differ by at most one)."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def balanced_shards(costs, world):
+    """Greedy longest-processing-time assignment of items (e.g. rasters weighted by padded point count) to
+    ranks; returns a list of index lists.  Raster sizes of one tree range over 1..6112 points, so contiguous
+    sharding would leave ranks idle."""
+    order = sorted(range(len(costs)), key=lambda i: -costs[i])
+    loads, out = [0.0] * world, [[] for _ in range(world)]
+    for i in order:
+        r = loads.index(min(loads))
+        out[r].append(i)
+        loads[r] += costs[i]
+    return [sorted(s) for s in out]

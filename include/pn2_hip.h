@@ -1,0 +1,119 @@
+/*
+ * pn2_hip.h -- C ABI of libpn2hip.so, the MI355X (gfx950) implementation of the PointNet++ hot path.
+ *
+ * The reference has no FFI boundary of its own for this path: the boundary is the Python API of
+ * Modules/PointNet2/pointnet2_utils.py and blocks.py.  Each entry point below replaces the
+ * device work of one reference expression group; the Python mirror that keeps the reference's signatures
+ * (extracting-tree-morphology-from-point-clouds_amd/PointNet2/) binds these symbols with ctypes, and
+ * INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into caller-owned memory; the library never allocates, frees or
+ *     synchronises.  Work is enqueued on `stream` (a hipStream_t passed as void*).
+ *   - return value: 0 ok; negative = rejected arguments (PN2_E_*); positive = hipError_t of a failed launch.
+ *   - coordinates/features are addressed as base + b*sb + n*sn + c*sc (strides in ELEMENTS), so both the
+ *     reference's [B,N,3] tensors and permuted views of its channel-first [B,3,N] tensors are accepted
+ *     without a copy.  Outputs are dense row-major.
+ *   - indices are int32 on the device side (the Python mirror widens to torch.long where the reference
+ *     API returns it).
+ *   - all arithmetic is fp32 with the operation order of the reference's CPU path (see oracle/pn2_oracle.c).
+ */
+#ifndef PN2_HIP_H
+#define PN2_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PN2_E_BADARG (-1)   /* null pointer / non-positive size / unsupported size */
+#define PN2_E_WORKSPACE (-2) /* workspace too small */
+
+#define PN2_ABI_VERSION 1
+
+/* ABI version of the loaded library (compare with PN2_ABI_VERSION). */
+int pn2_version(void);
+
+/* Static description of the code object, e.g. "gfx950". */
+const char *pn2_arch(void);
+
+/* ---------------------------------------------------------------------------------------------------
+ * square_distance                  replaces Modules/PointNet2/pointnet2_utils.py:21-42
+ *   out [B,N,M] = ((-2 * src.dst) + |src|^2) + |dst|^2, the reference's expansion (not the direct distance).
+ *   API completeness only: ball query and three_nn evaluate the same expression without materialising it.
+ */
+int pn2_square_distance_f32(const float *src, int64_t ab, int64_t an, int64_t ac, const float *dst, int64_t bb,
+                            int64_t bn, int64_t bc, int B, int N, int M, float *out, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * farthest_point_sample            replaces Modules/PointNet2/pointnet2_utils.py:66-89
+ *   start    [B] int64   first centroid per cloud (the reference's torch.randint draw, line 79)
+ *   out_idx  [B,npoint] int32
+ *   out_xyz  [B,npoint,3] f32 or NULL -- the gathered centroids (index_points(xyz, idx), line 154)
+ *   workspace: pn2_fps_workspace_bytes(B,N,npoint) bytes, contents irrelevant on entry.
+ */
+size_t pn2_fps_workspace_bytes(int B, int N, int npoint);
+int pn2_fps_f32(const float *xyz, int64_t sb, int64_t sn, int64_t sc, int B, int N, int npoint,
+                const int64_t *start, int32_t *out_idx, float *out_xyz, void *workspace,
+                size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * query_ball_point                 replaces Modules/PointNet2/pointnet2_utils.py:92-136
+ *   r2       float32(double(radius)**2); a point is inside unless d > r2
+ *   out_idx  [B,S,Keff] int32, Keff = min(nsample, N): first Keff inside indices ascending, short rows
+ *            padded with their first entry, empty balls filled with argmin of the row.
+ *   workspace: pn2_ball_query_workspace_bytes(B,N,S,nsample) bytes.
+ */
+size_t pn2_ball_query_workspace_bytes(int B, int N, int S, int nsample);
+int pn2_ball_query_f32(const float *xyz, int64_t sb, int64_t sn, int64_t sc, const float *new_xyz,
+                       int64_t qb, int64_t qn, int64_t qc, int B, int N, int S, float r2, int nsample,
+                       int32_t *out_idx, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * group_points (+ centring + concat)   replaces index_points x2 and lines 156-161 of sample_and_group
+ *   out [B,S,K,3+D]: channels [xyz - new_xyz, feats] or, with xyz_last != 0, [feats, xyz - new_xyz]
+ *   (the MSG order, blocks.py:143-146).  feats may be NULL with D = 0.
+ */
+int pn2_group_f32(const float *xyz, int64_t sb, int64_t sn, int64_t sc, const float *new_xyz,
+                  const float *feats, int64_t fb, int64_t fn, int64_t fc, const int32_t *idx, int B, int N,
+                  int S, int K, int D, int xyz_last, float *out, void *stream);
+
+/* gradient w.r.t. feats: dfeats [B,N,D] (dense, zeroed by the call) += dout[..., feature channels] */
+int pn2_group_grad_f32(const float *dout, const int32_t *idx, int B, int N, int S, int K, int D,
+                       int xyz_last, float *dfeats, void *stream);
+
+/* plain index_points: out[b][s][:] = points[b][idx[b][s]][:]   (pointnet2_utils.py:45-63) */
+int pn2_gather_f32(const float *points, int64_t pb, int64_t pn, int64_t pc, const int32_t *idx, int B, int N,
+                   int S, int C, float *out, void *stream);
+int pn2_gather_grad_f32(const float *dout, const int32_t *idx, int B, int N, int S, int C, float *dpoints,
+                        void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * three_nn                          replaces Modules/PointNet2/blocks.py:194-203
+ *   for every xyz1 point the 3 smallest square_distance(xyz1, xyz2) entries, ties -> lower index first;
+ *   out_idx [B,N,3] int32, out_w [B,N,3] normalised inverse-distance weights, out_dist [B,N,3] or NULL.
+ *   Requires S >= 3.
+ */
+int pn2_three_nn_f32(const float *xyz1, int64_t ab, int64_t an, int64_t ac, const float *xyz2, int64_t bb,
+                     int64_t bn, int64_t bc, int B, int N, int S, int32_t *out_idx, float *out_w,
+                     float *out_dist, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * three_interpolate                 replaces Modules/PointNet2/blocks.py:204
+ *   points2 [B,S,D] (strided), out rows of out_stride floats; the D interpolated channels are written at
+ *   column out_offset (so the skip-connection concat of blocks.py:208 needs no extra copy).
+ */
+int pn2_three_interpolate_f32(const float *points2, int64_t pb, int64_t pn, int64_t pc, const int32_t *idx,
+                              const float *w, int B, int N, int S, int D, float *out, int64_t out_stride,
+                              int64_t out_offset, void *stream);
+/* dpoints2 [B,S,D] (dense, zeroed by the call) += w * dout[:, out_offset : out_offset+D] */
+int pn2_three_interpolate_grad_f32(const float *dout, int64_t out_stride, int64_t out_offset,
+                                   const int32_t *idx, const float *w, int B, int N, int S, int D,
+                                   float *dpoints2, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PN2_HIP_H */
