@@ -322,39 +322,69 @@ def test_conv_head_golden(pn2):
 
 
 # --------------------------------------------------------------------------------------------- golden: models
+def seeded_model(cls, g, depth):
+    """Default (random) init reproduced by seed -- same nn modules created in the same order as the reference --
+    and verified against the per-parameter checksums stored with the fixture."""
+    torch.manual_seed(int(g["weight_seed"]))
+    model = cls(depth=depth)
+    ps = sorted(model.named_parameters(), key=lambda kv: kv[0])
+    assert [n for n, _ in ps] == [str(n) for n in g["grad_names"]]
+    got_sum = np.array([float(p.detach().double().sum()) for _, p in ps])
+    got_abs = np.array([float(p.detach().double().abs().sum()) for _, p in ps])
+    np.testing.assert_allclose(got_sum, g["param_sum"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(got_abs, g["param_abs"], rtol=1e-12)
+    return model
+
+
+def close_to_reference(got, ref32, ref64, what, tol=RTOL):
+    """The bar for float outputs of a whole network: within `tol` x (largest magnitude) of the reference evaluated
+    with float64 layer arithmetic, and no further from the reference's fp32 output than tol + the reference's own
+    distance from that float64 evaluation (networks of this depth amplify fp32 rounding to 1e-5..1e-4)."""
+    got = got.detach().cpu().numpy()
+    scale = float(np.abs(ref64).max())
+    e_ref = float(np.abs(ref32 - ref64).max())
+    e_got = float(np.abs(got - ref64).max())
+    e_dir = float(np.abs(got - ref32).max())
+    msg = f"{what}: |hip-f64| {e_got / scale:.2e}, |ref32-f64| {e_ref / scale:.2e}, |hip-ref32| {e_dir / scale:.2e} (of max)"
+    print(msg)
+    assert e_got <= tol * scale, msg
+    assert e_dir <= tol * scale + e_ref, msg
+
+
 @pytest.mark.parametrize("depth", [5, 4, 6, 3, 2])
 def test_model_golden(pn2, depth):
-    """Whole forward + loss + backward of PointNet2 against the imported reference: FPS starts must coincide
-    (same RNG stream), per-point offsets within 1e-4 relative, losses to 1e-5, parameter gradients to 2e-4 of
-    each gradient's largest entry."""
+    """Whole forward + loss + backward of PointNet2 against the imported reference: same FPS starts (same RNG
+    stream), per-point offsets within 1e-4 relative, losses to 1e-4, parameter gradient norms to 5e-4."""
     from pn2_amd.PointNet2.PointNet2 import PointNet2
     g = gold(f"model_d{depth}.npz")
-    model = PointNet2(depth=depth)
-    helpers.closed_form_init(model)
-    model.cuda().train()
+    model = seeded_model(PointNet2, g, depth).cuda().train()
     batch = {k: dev(g[k]) for k in ["coords", "feats", "masks_pad", "masks_off", "semantic_labels", "offset_labels"]}
     torch.manual_seed(int(g["torch_seed"]))
     loss, ld = model(batch, return_loss=True)
     (loss * 50).backward()
-    assert abs(float(loss) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"])) + 1e-6
-    assert abs(float(ld["offset_loss"]) - float(g["offset_loss"])) <= 1e-5 * abs(float(g["offset_loss"])) + 1e-6
-    assert abs(float(ld["semantic_loss"]) - float(g["semantic_loss"])) <= 1e-5 * abs(float(g["semantic_loss"])) + 1e-6
+    assert abs(float(loss.detach()) - float(g["loss_f64"])) <= 1e-4 * abs(float(g["loss_f64"]))
+    assert abs(float(loss.detach()) - float(g["loss"])) <= 1e-4 * abs(float(g["loss"]))
+    assert abs(float(ld["offset_loss"].detach()) - float(g["offset_loss"])) <= 1e-4 * abs(float(g["offset_loss"]))
+    assert abs(float(ld["semantic_loss"].detach()) - float(g["semantic_loss"])) <= 1e-4 * abs(float(g["semantic_loss"]))
 
     params = dict(model.named_parameters())
-    gmax = float(g["grad_l2"].max())          # absolute floor: gradients that all but vanish are rounding noise
-    for name, l2 in zip(g["grad_names"], g["grad_l2"]):
-        got = float(params[str(name)].grad.double().norm())
-        if helpers.is_pre_bn_bias(str(name)):
-            wn = float(params[str(name)[:-4] + "weight"].grad.double().norm())
+    gmax = float(g["grad_l2_f64"].max())       # absolute floor: gradients that all but vanish are rounding noise
+    for name, l2, l2_64 in zip(g["grad_names"], g["grad_l2"], g["grad_l2_f64"]):
+        name = str(name)
+        got = float(params[name].grad.double().norm())
+        if helpers.is_pre_bn_bias(name):
+            wn = float(params[name[:-4] + "weight"].grad.double().norm())
             assert got <= 1e-2 * wn, f"{name}: pre-BN bias gradient should vanish, got {got} (weight grad {wn})"
         else:
-            # depth 6: r = 0.02 balls mostly hold one point -> near-zero-variance BatchNorm channels amplify
-            # rounding noise by 1/sqrt(eps); the torch-CPU restatement itself only reproduces these to ~1e-3
-            tol = 3e-3 if depth == 6 else 5e-4
-            assert abs(got - l2) <= tol * l2 + 1e-6 * gmax, f"grad norm of {name}: {got} vs {l2}"
+            bar = max(5e-4 * l2_64, 3 * abs(l2 - l2_64)) + 1e-6 * gmax
+            assert abs(got - l2_64) <= bar, f"grad norm of {name}: hip {got}, ref32 {l2}, ref f64 {l2_64}"
     for key in g.files:
         if key.startswith("g__") and not helpers.is_pre_bn_bias(key[3:]):
-            grad_close(params[key[3:]].grad, g[key], f"depth {depth} grad {key[3:]}", rel=3e-3 if depth == 6 else GRAD_REL)
+            ref32, ref64 = g[key], g["g64__" + key[3:]]
+            got = params[key[3:]].grad.detach().cpu().numpy()
+            scale = float(np.abs(ref64).max())
+            bar = max(GRAD_REL * scale, 3 * float(np.abs(ref32 - ref64).max()))
+            assert float(np.abs(got - ref64).max()) <= bar, f"depth {depth} grad {key[3:]}"
     bufs = dict(model.named_buffers())
     for key in g.files:
         if key.startswith("buf__"):
@@ -363,9 +393,9 @@ def test_model_golden(pn2, depth):
     torch.manual_seed(int(g["torch_seed"]))
     with torch.no_grad():
         out = model(batch, return_loss=False)
-    close(out["offset_predictions"], g["offset_predictions"], what=f"depth {depth} offsets")
-    close(out["semantic_prediction_logits"], g["semantic_logits"], what=f"depth {depth} logits")
-    close(out["backbone_feats"][:, :, :64], g["backbone_head"], what=f"depth {depth} backbone feats")
+    close_to_reference(out["offset_predictions"], g["offset_predictions"], g["offset_predictions_f64"], f"depth {depth} offsets")
+    close_to_reference(out["semantic_prediction_logits"], g["semantic_logits"], g["semantic_logits_f64"], f"depth {depth} logits")
+    close_to_reference(out["backbone_feats"][:, :, :64], g["backbone_head"], g["backbone_head_f64"], f"depth {depth} backbone")
 
 
 # ----------------------------------------------------------------------------------- full size (BASELINE config 2)
