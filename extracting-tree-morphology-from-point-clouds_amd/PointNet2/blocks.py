@@ -82,8 +82,8 @@ class MLP(nn.Sequential):
 def _group_mlp_max(grouped, convs, bns):
     """grouped [B,S,K,C] -> per-group MLP and max over K -> [B,S,C_out] (reference blocks.py:93-98)."""
     B, S, K, C = grouped.shape
-    y = chain_rows(grouped.reshape(B * S * K, C), [(c, b, True) for c, b in zip(convs, bns)])
-    return y.view(B, S, K, -1).max(dim=2)[0]
+    y = chain_rows(grouped.reshape(B * S * K, C), [(c, b, True) for c, b in zip(convs, bns)], pool_k=K)
+    return y.view(B, S, -1)
 
 
 class PointNetSetAbstraction(nn.Module):

@@ -17,6 +17,18 @@ _int = ctypes.c_int
 _f32 = ctypes.c_float
 _sz = ctypes.c_size_t
 
+
+
+class MLPLayer(ctypes.Structure):
+    """struct pn2_mlp_layer of include/pn2_hip.h (field order and types must match)."""
+    _fields_ = [("cin", ctypes.c_int32), ("cout", ctypes.c_int32), ("weight", _vp), ("bias", _vp),
+                ("has_bn", ctypes.c_int32), ("relu", ctypes.c_int32), ("gamma", _vp), ("beta", _vp),
+                ("running_mean", _vp), ("running_var", _vp), ("eps", _f32), ("momentum", _f32),
+                ("y", _vp), ("stats", _vp), ("dweight", _vp), ("dbias", _vp), ("dgamma", _vp), ("dbeta", _vp)]
+
+
+_lp = ctypes.POINTER(MLPLayer)
+
 # name -> (restype, argtypes); must list every symbol include/pn2_hip.h declares (tests/test_abi.py checks)
 SIGNATURES = {
     "pn2_version": (_int, []),
@@ -35,6 +47,9 @@ SIGNATURES = {
     "pn2_three_nn_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _int, _int, _int, _vp, _vp, _vp, _vp]),
     "pn2_three_interpolate_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _int, _int, _int, _int, _vp, _i64, _i64, _vp]),
     "pn2_three_interpolate_grad_f32": (_int, [_vp, _i64, _i64, _vp, _vp, _int, _int, _int, _int, _vp, _vp]),
+    "pn2_mlp_workspace_bytes": (_sz, [_int, _lp, _int]),
+    "pn2_mlp_chain_fwd_f32": (_int, [_vp, _i64, _int, _lp, _int, _int, _int, _vp, _vp, _vp, _sz, _vp]),
+    "pn2_mlp_chain_bwd_f32": (_int, [_vp, _i64, _int, _lp, _int, _int, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
 }
 
 _lib = None

@@ -1,35 +1,168 @@
-"""Pointwise (1x1-conv) MLP chains on channels-last rows.
+"""Pointwise (1x1-conv) MLP chains on channels-last rows, served by libpn2hip's MFMA chain kernels.
 
-Every MLP of the hot path -- the per-group Conv2d/BatchNorm2d/ReLU stacks of set abstraction (reference
-blocks.py:93-98), the Conv1d/BatchNorm1d/ReLU stacks of feature propagation (:213-215) and the ConvHead
-(:7-35) -- is a chain of ``rows x C_in -> rows x C_out`` contractions with per-channel batch statistics over
-all rows.  The modules keep the reference's parameter containers (so state-dict keys and shapes are
-unchanged) and hand their layers to ``chain_rows``.
+Every MLP of the hot path -- the per-group Conv2d/BatchNorm2d/ReLU stacks + max over K of set abstraction
+(reference blocks.py:93-98), the Conv1d/BatchNorm1d/ReLU stacks of feature propagation (:213-215) and the
+ConvHead (:7-35) -- is a chain of ``rows x C_in -> rows x C_out`` contractions with per-channel batch statistics
+over all rows.  The modules keep the reference's parameter containers (state-dict keys and shapes unchanged)
+and hand their layers to ``chain_rows``; one C-ABI call runs the whole chain forward, one runs it backward
+(include/pn2_hip.h: pn2_mlp_chain_{fwd,bwd}_f32).
 """
+import ctypes
+
 import torch
-import torch.nn.functional as F
+
+from . import _hip
 
 
-def _batch_norm_rows(bn, y):
-    """BatchNorm over the row dimension with nn.BatchNorm*d's bookkeeping (momentum, num_batches_tracked)."""
-    use_batch = bn.training or bn.running_mean is None
-    factor = 0.0 if bn.momentum is None else bn.momentum
+def _bn_momentum(bn):
+    """nn.BatchNorm bookkeeping on the host side: bump num_batches_tracked, resolve momentum=None."""
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
         if bn.momentum is None:
-            factor = 1.0 / float(bn.num_batches_tracked)
-    return F.batch_norm(y, bn.running_mean if (not bn.training or bn.track_running_stats) else None,
-                        bn.running_var if (not bn.training or bn.track_running_stats) else None,
-                        bn.weight, bn.bias, use_batch, factor, bn.eps)
+            return 1.0 / float(bn.num_batches_tracked)
+    return 0.0 if bn.momentum is None else float(bn.momentum)
 
 
-def chain_rows(x, layers):
-    """x [R, C_in] fp32 contiguous rows; layers: iterable of (conv, bn_or_None, relu: bool).  -> [R, C_out]."""
+class _ChainFn(torch.autograd.Function):
+    """forward(x [R,Cin], meta, *params) -> out; params = (weight, bias, gamma, beta) per layer (None allowed)."""
+
+    @staticmethod
+    def forward(ctx, x, meta, *params):
+        _hip.require_device(x)
+        lib = _hip.lib()
+        x = _hip.f32(x)
+        if x.stride(1) != 1:
+            x = x.contiguous()
+        rows, cin0 = x.shape
+        n = len(meta["layers"])
+        pool_k, training = meta["pool_k"], meta["training"]
+        dev = x.device
+        arr = (_hip.MLPLayer * n)()
+        ys, stats = [], []
+        cin = cin0
+        for i, spec in enumerate(meta["layers"]):
+            w, b, g, be = params[4 * i:4 * i + 4]
+            cout = spec["cout"]
+            L = arr[i]
+            L.cin, L.cout = cin, cout
+            L.weight, L.bias = w.data_ptr(), _hip.ptr(b)
+            L.has_bn, L.relu = int(spec["has_bn"]), int(spec["relu"])
+            L.gamma, L.beta = _hip.ptr(g), _hip.ptr(be)
+            L.running_mean, L.running_var = _hip.ptr(spec["running_mean"]), _hip.ptr(spec["running_var"])
+            L.eps, L.momentum = spec["eps"], spec["momentum"]
+            last = i == n - 1
+            if last and not spec["has_bn"] and pool_k <= 1:
+                y = None                                          # the chain writes `out` directly
+            else:
+                y = torch.empty(rows, cout, dtype=torch.float32, device=dev)
+            st = torch.empty(8, cout, dtype=torch.float32, device=dev) if spec["has_bn"] else None
+            L.y, L.stats = _hip.ptr(y), _hip.ptr(st)
+            ys.append(y)
+            stats.append(st)
+            cin = cout
+        cout_last = cin
+        if pool_k > 1:
+            out = torch.empty(rows // pool_k, cout_last, dtype=torch.float32, device=dev)
+            arg = torch.empty(rows // pool_k, cout_last, dtype=torch.int32, device=dev)
+        else:
+            out = torch.empty(rows, cout_last, dtype=torch.float32, device=dev)
+            arg = None
+        ws = torch.empty(lib.pn2_mlp_workspace_bytes(rows, arr, n), dtype=torch.uint8, device=dev)
+        flops = 2 * rows * sum(int(a.cin) * int(a.cout) for a in arr)
+        nbytes = 4 * rows * (cin0 + 2 * sum(int(a.cout) for a in arr))
+        _hip.call("mlp_chain_fwd", lib.pn2_mlp_chain_fwd_f32, x.data_ptr(), x.stride(0), rows, arr, n, int(training),
+                  int(pool_k), out.data_ptr(), _hip.ptr(arg), ws.data_ptr(), ws.numel(), _hip.stream_ptr(),
+                  nbytes=nbytes, flops=flops)
+        ctx.meta = meta
+        ctx.dims = (rows, cin0)
+        ctx.save_for_backward(x, arg, *[t for t in ys if t is not None], *[t for t in stats if t is not None], *params)
+        ctx.layout = ([t is not None for t in ys], [t is not None for t in stats])
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _hip.lib()
+        meta = ctx.meta
+        if not meta["training"] and any(sp["has_bn"] for sp in meta["layers"]):
+            raise NotImplementedError("backward through eval-mode BatchNorm is not part of the hot path")
+        rows, cin0 = ctx.dims
+        n = len(meta["layers"])
+        saved = list(ctx.saved_tensors)
+        x, arg = saved[0], saved[1]
+        has_y, has_st = ctx.layout
+        pos = 2
+        ys = []
+        for h in has_y:
+            ys.append(saved[pos] if h else None)
+            pos += int(h)
+        stats = []
+        for h in has_st:
+            stats.append(saved[pos] if h else None)
+            pos += int(h)
+        params = saved[pos:]
+        dev = x.device
+        dout = dout.contiguous()
+        arr = (_hip.MLPLayer * n)()
+        grads = []
+        cin, maxc = cin0, 0
+        for i, spec in enumerate(meta["layers"]):
+            w, b, g, be = params[4 * i:4 * i + 4]
+            cout = spec["cout"]
+            L = arr[i]
+            L.cin, L.cout = cin, cout
+            L.weight, L.bias = w.data_ptr(), _hip.ptr(b)
+            L.has_bn, L.relu = int(spec["has_bn"]), int(spec["relu"])
+            L.gamma, L.beta = _hip.ptr(g), _hip.ptr(be)
+            L.eps, L.momentum = spec["eps"], spec["momentum"]
+            L.y, L.stats = _hip.ptr(ys[i]), _hip.ptr(stats[i])
+            need = ctx.needs_input_grad[2 + 4 * i:2 + 4 * i + 4]
+            dw = torch.zeros_like(w) if need[0] else None
+            # bias of a conv that feeds a train-mode BatchNorm: the gradient is identically zero
+            db = torch.zeros_like(b) if (b is not None and need[1]) else None
+            dg = torch.zeros_like(g) if (g is not None and need[2]) else None
+            dbe = torch.zeros_like(be) if (be is not None and need[3]) else None
+            L.dweight = _hip.ptr(dw)
+            L.dbias = None if spec["has_bn"] else _hip.ptr(db)
+            L.dgamma, L.dbeta = _hip.ptr(dg), _hip.ptr(dbe)
+            grads += [dw, db, dg, dbe]
+            if i > 0:
+                maxc = max(maxc, cin)
+            cin = cout
+        maxc = max(maxc, cin)
+        dx = torch.empty(rows, cin0, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        sa = torch.empty(rows * maxc, dtype=torch.float32, device=dev)
+        sb = torch.empty(rows * maxc, dtype=torch.float32, device=dev)
+        ws = torch.empty(lib.pn2_mlp_workspace_bytes(rows, arr, n), dtype=torch.uint8, device=dev)
+        flops = 4 * rows * sum(int(a.cin) * int(a.cout) for a in arr)
+        nbytes = 4 * rows * (cin0 + 5 * sum(int(a.cout) for a in arr))
+        _hip.call("mlp_chain_bwd", lib.pn2_mlp_chain_bwd_f32, x.data_ptr(), x.stride(0), rows, arr, n, int(meta["pool_k"]),
+                  dout.data_ptr(), _hip.ptr(arg), _hip.ptr(dx), cin0, sa.data_ptr(), sb.data_ptr(), ws.data_ptr(), ws.numel(),
+                  _hip.stream_ptr(), nbytes=nbytes, flops=flops)
+        return (dx, None, *grads)
+
+
+def chain_rows(x, layers, pool_k=1):
+    """x [R, C_in] fp32 rows; layers: iterable of (conv, bn_or_None, relu: bool).
+    -> [R, C_out], or [R // pool_k, C_out] (max over each group of pool_k consecutive rows) when pool_k > 1."""
+    layers = list(layers)
+    if not layers:
+        return x
+    specs, params, training = [], [], False
     for conv, bn, relu in layers:
         w = conv.weight.reshape(conv.out_channels, -1)
-        x = F.linear(x, w, conv.bias)
+        spec = {"cout": conv.out_channels, "has_bn": bn is not None, "relu": bool(relu), "eps": 0.0, "momentum": 0.0,
+                "running_mean": None, "running_var": None}
         if bn is not None:
-            x = _batch_norm_rows(bn, x)
-        if relu:
-            x = F.relu(x)
-    return x
+            use_batch = bn.training or bn.running_mean is None
+            training = training or use_batch
+            spec["momentum"] = _bn_momentum(bn)
+            spec["eps"] = float(bn.eps)
+            if bn.track_running_stats and bn.running_mean is not None:
+                spec["running_mean"], spec["running_var"] = bn.running_mean, bn.running_var
+            params += [w, conv.bias, bn.weight, bn.bias]
+        else:
+            params += [w, conv.bias, None, None]
+        specs.append(spec)
+    # a chain is either all batch statistics or all running statistics (module.train()/eval() sets them together)
+    meta = {"layers": specs, "pool_k": int(pool_k), "training": training}
+    return _ChainFn.apply(x, meta, *params)

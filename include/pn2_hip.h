@@ -113,6 +113,49 @@ int pn2_three_interpolate_grad_f32(const float *dout, int64_t out_stride, int64_
                                    const int32_t *idx, const float *w, int B, int N, int S, int D,
                                    float *dpoints2, void *stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Pointwise MLP chains: (1x1 conv -> BatchNorm -> ReLU) x n [-> max over groups of pool_k rows]
+ *   replaces the Conv2d/BatchNorm2d/ReLU/max stack of Modules/PointNet2/blocks.py:93-98 (set abstraction),
+ *   the Conv1d/BatchNorm1d/ReLU stack of :213-215 (feature propagation) and ConvHead :7-35, fwd and bwd.
+ *
+ * Activations are channels-last rows: x [rows][cin_0] with row stride ldx.  Layer i computes
+ *   y_i = act_{i-1} W_i^T + b_i,   act_i = relu?(BatchNorm(y_i))  (train: batch statistics over all rows,
+ *   running stats updated like nn.BatchNorm; eval: running stats),
+ * y_i (pre-BatchNorm) is kept in layers[i].y for the backward pass and the normalised activation is never
+ * written except for the chain's output:
+ *   pool_k <= 1: out [rows][cout_last] = act_last        (a last layer without BatchNorm writes y itself)
+ *   pool_k  > 1: out [rows/pool_k][cout_last] = max over each group of pool_k consecutive rows, pool_arg
+ *                [rows/pool_k][cout_last] int32 = first row offset attaining it (torch.max's choice).
+ * stats: [8][cout] floats per BatchNorm layer (mean, biased var, invstd, gamma*invstd, beta, and two rows
+ * written by the backward pass); running_mean/var may be NULL (no tracking).
+ *
+ * Backward: dout has the shape of out; gradients are ACCUMULATED (+=) into dweight/dbias/dgamma/dbeta where
+ * non-NULL (dbias of a conv feeding a BatchNorm is analytically zero and is left untouched); dx [rows][cin_0]
+ * (row stride lddx) is written when non-NULL.  scratch_a/b: two buffers of rows * max(cin_i, cout_last) floats.
+ * workspace: pn2_mlp_workspace_bytes(rows, layers, nlayers) bytes for either direction.
+ */
+typedef struct pn2_mlp_layer {
+    int32_t cin, cout;
+    const float *weight;       /* [cout][cin] */
+    const float *bias;         /* [cout] or NULL */
+    int32_t has_bn, relu;
+    const float *gamma, *beta; /* [cout] or NULL (1, 0) */
+    float *running_mean, *running_var;
+    float eps, momentum;
+    float *y;                  /* [rows][cout] pre-BatchNorm output (written by fwd, read by bwd) */
+    float *stats;              /* [8][cout] */
+    float *dweight, *dbias, *dgamma, *dbeta;
+} pn2_mlp_layer;
+
+size_t pn2_mlp_workspace_bytes(int rows, const pn2_mlp_layer *layers, int nlayers);
+int pn2_mlp_chain_fwd_f32(const float *x, int64_t ldx, int rows, const pn2_mlp_layer *layers, int nlayers,
+                          int training, int pool_k, float *out, int32_t *pool_arg, void *workspace,
+                          size_t workspace_bytes, void *stream);
+int pn2_mlp_chain_bwd_f32(const float *x, int64_t ldx, int rows, const pn2_mlp_layer *layers, int nlayers,
+                          int pool_k, const float *dout, const int32_t *pool_arg, float *dx, int64_t lddx,
+                          float *scratch_a, float *scratch_b, void *workspace, size_t workspace_bytes,
+                          void *stream);
+
 #ifdef __cplusplus
 }
 #endif
