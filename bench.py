@@ -6,8 +6,8 @@
 A step = zero grads, PointNet2.forward (SA x4, FP x4, heads), offset-regression loss, backward of 50*loss, one
 gradient all-reduce (N > 1) and the AdamW update -- one pass of the hot path over one batch (one tree per rank:
 weak scaling, no data-path collective).  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE
-JSON line: the contract fields plus `roofline` (dominant libpn2hip kernel, HIP-event timed on its launch stream
-during a second, instrumented run of the same steps) and `cpu_baseline` (oracle/torch_port.py, the torch-CPU
+JSON line: the contract fields plus `roofline` (dominant libpn2hip kernel at its dominant launch shape, HIP-event timed
+on its launch stream during a second, instrumented run of the same steps) and `cpu_baseline` (oracle/torch_port.py, the torch-CPU
 restatement of the reference path, timed on this box's host cores; rank 0, N = 1 only).
 """
 import argparse
@@ -111,33 +111,37 @@ def main():
         dt = float(t)
     assert torch.isfinite(loss).item()
 
-    # second, instrumented run of the same steps: HIP events around every libpn2hip launch
-    _hip.timer.reset()
-    _hip.timer.enabled = True
-    for _ in range(args.steps):
-        step()
-    _hip.timer.enabled = False
-    prof = _hip.timer.summary()
+    # second, instrumented run of the same steps: the library brackets every kernel launch with HIP events on its
+    # launch stream (pn2_prof_enable) and aggregates per (kernel, launch shape)
+    def timed_steps():
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+    groups = _hip.kernel_profile(timed_steps)
     barrier()
 
     if rank == 0:
+        step_ms = 1e3 * dt / args.steps
         kernels = {}
-        for name, d in prof.items():
-            per = d["ms"] / d["calls"]
-            kernels[name] = {"calls_per_step": d["calls"] / args.steps, "ms_per_step": d["ms"] / args.steps,
-                             "avg_launch_us": 1e3 * per,
-                             "algorithmic_GBs": (d["bytes"] / d["calls"]) / (per * 1e-3) / 1e9 if per > 0 else 0.0}
-        dom = max(prof, key=lambda n: prof[n]["ms"])
-        d = prof[dom]
-        # the dominant entry point may be launched at several shapes per step (one per level); the roofline
-        # object is for its largest launch, which carries almost all of its time
-        big = max((r for r in _hip.timer.records if r[0] == dom), key=lambda r: r[3].elapsed_time(r[4]))
-        same = [r for r in _hip.timer.records if r[0] == dom and r[1] == big[1]]
-        avg_ms = sum(r[3].elapsed_time(r[4]) for r in same) / len(same)
-        achieved = big[1] / (avg_ms * 1e-3) / 1e9
-        roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes_per_launch": big[1],
-                    "avg_launch_us": 1e3 * avg_ms, "share_of_step": d["ms"] / args.steps / (1e3 * dt / args.steps)}
+        for gr in groups:
+            k = kernels.setdefault(gr["name"], {"launches_per_step": 0.0, "ms_per_step": 0.0})
+            k["launches_per_step"] += gr["calls"] / args.steps
+            k["ms_per_step"] += gr["ms"] / args.steps
+        for k in kernels.values():
+            k["share_of_step"] = k["ms_per_step"] / step_ms
+        dom = max(groups, key=lambda gr: gr["ms"])            # dominant (kernel, shape) by total time
+        avg_s = dom["ms"] / dom["calls"] * 1e-3
+        hbm = dom["bytes"] / avg_s / 1e9
+        tfl = dom["flops"] / avg_s / 1e12
+        if dom["flops"] > 0 and tfl / F32_MFMA_PEAK_TFLOPS > hbm / HBM_PEAK_GBS:
+            roofline = {"kernel": dom["name"], "bound": "mfma", "achieved": tfl, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": tfl / F32_MFMA_PEAK_TFLOPS, "traffic": None, "hbm_GBs": hbm, "hbm_frac": hbm / HBM_PEAK_GBS}
+        else:
+            roofline = {"kernel": dom["name"], "bound": "hbm", "achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": hbm / HBM_PEAK_GBS, "traffic": None}
+        roofline.update({"algorithmic_bytes_per_launch": dom["bytes"], "algorithmic_flops_per_launch": dom["flops"],
+                         "avg_launch_us": 1e6 * avg_s, "launches_per_step": dom["calls"] / args.steps,
+                         "share_of_step": dom["ms"] / args.steps / step_ms})
         out = {
             "metric": "points/sec fwd+bwd, PointNet2 offset-regression, 262k-pt tree, 1/2/4/8 GPUs",
             "value": args.points * world * args.steps / dt, "unit": "points/s", "n_gpus": world, "steps": args.steps,

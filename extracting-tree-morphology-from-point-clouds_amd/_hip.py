@@ -47,6 +47,9 @@ SIGNATURES = {
     "pn2_three_nn_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _int, _int, _int, _vp, _vp, _vp, _vp]),
     "pn2_three_interpolate_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _int, _int, _int, _int, _vp, _i64, _i64, _vp]),
     "pn2_three_interpolate_grad_f32": (_int, [_vp, _i64, _i64, _vp, _vp, _int, _int, _int, _int, _vp, _vp]),
+    "pn2_prof_enable": (None, [_int]),
+    "pn2_prof_collect": (_int, [ctypes.c_char_p, _sz, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong),
+                                ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _int]),
     "pn2_mlp_workspace_bytes": (_sz, [_int, _lp, _int]),
     "pn2_mlp_chain_fwd_f32": (_int, [_vp, _i64, _int, _lp, _int, _int, _int, _vp, _vp, _vp, _sz, _vp]),
     "pn2_mlp_chain_bwd_f32": (_int, [_vp, _i64, _int, _lp, _int, _int, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
@@ -137,3 +140,29 @@ def call(name, fn, *args, nbytes=0, flops=0):
     else:
         status = fn(*args)
     check(status, name)
+
+
+def kernel_profile(fn):
+    """Run fn() with the library's per-kernel HIP-event timing on; returns a list of dicts
+    (name, calls, ms, bytes, flops) where bytes/flops are the ALGORITHMIC figures of ONE launch of that group."""
+    L = lib()
+    L.pn2_prof_enable(1)
+    try:
+        fn()
+    finally:
+        L.pn2_prof_enable(0)
+    cap, maxg = 1 << 16, 1024
+    names = ctypes.create_string_buffer(cap)
+    ms = (ctypes.c_double * maxg)()
+    calls = (ctypes.c_longlong * maxg)()
+    nbytes = (ctypes.c_double * maxg)()
+    flops = (ctypes.c_double * maxg)()
+    n = L.pn2_prof_collect(names, cap, ms, calls, nbytes, flops, maxg)
+    out, raw = [], names.raw
+    pos = 0
+    for i in range(n):
+        end = raw.index(b"\0", pos)
+        out.append({"name": raw[pos:end].decode(), "calls": int(calls[i]), "ms": float(ms[i]), "bytes": float(nbytes[i]),
+                    "flops": float(flops[i])})
+        pos = end + 1
+    return out

@@ -3,17 +3,22 @@
 // FPS is npoint strictly sequential argmax steps, so the bound is the latency of one step, not bandwidth.
 // Layout: every cloud is owned by a *group* of G workgroups (G = 1 for small clouds).  Each thread keeps
 // PPT points and their running minimum distance in registers for the whole kernel (xyz is read from HBM
-// exactly once: 12 B/point), a step is
-//     register update -> wave max (DPP shuffles) -> LDS max over the workgroup's waves
-//     -> [G > 1] one 8-byte granule per workgroup, stored write-through and polled by one wave of every
-//        member workgroup (data-is-the-flag hand-off, placement independent, no grid barrier)
-//     -> scalar load of the winner's coordinates.
+// exactly once: 12 B/point); a step is
+//     register update -> wave max (shuffles) -> LDS max over the workgroup's waves
+//     -> [G > 1] four 8-byte granules per workgroup {key | x | y | z}, stored write-through and polled by one
+//        wave of every member workgroup (data-is-the-flag hand-off, placement independent, no grid barrier).
+// The winner's coordinates travel WITH the key (registers -> LDS -> granules), so the next step never waits
+// on a dependent global load.
 // The argmax key is (dist_bits << 32) | ~index: distances are non-negative so their bit patterns order like
 // the values, and the complemented index makes the LOWEST index win ties exactly like torch.max does
 // (zero-padded clouds have many identical points).
 //
 // Granules are never reused inside a launch (one slot per (cloud, step, member)), the slot array is zeroed
-// by a memset node ahead of the kernel, bit 63 marks a written slot, and every spin is bounded.
+// by a memset node ahead of the kernel, every granule carries its own validity (bit 63 of the key granule,
+// the step number in the coordinate granules) and is written by ONE 8-byte store, and every spin is bounded.
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "pn2_common.h"
 
 namespace {
@@ -21,7 +26,23 @@ namespace {
 using u64 = unsigned long long;
 constexpr u64 kValid = 1ull << 63;
 constexpr int kMaxG = 64;
-constexpr unsigned kSpinLimit = 1u << 24;
+constexpr unsigned kSpinLimit = 1u << 22;
+#ifdef PN2_FPS_DIAG
+constexpr size_t kHdr = 256;
+#else
+constexpr size_t kHdr = 16;
+#endif
+
+__device__ __forceinline__ u64 ld_granule(const u64* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_granule(u64* p, u64 v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for vmcnt(0), i.e. for the
+// round trip of the (fire-and-forget) result stores of the step, which costs more than the step itself.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int PPT, int T>
 __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, int64_t sb, int64_t sn, int64_t sc,
@@ -30,7 +51,9 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
                                                 u64* gran, unsigned* err, int G, int groups) {
     constexpr int NW = T / 64;
     __shared__ u64 s_key[2][NW];
+    __shared__ float s_xyz[2][NW][3];
     __shared__ u64 s_win[2];
+    __shared__ float s_wxyz[2][3];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -53,12 +76,31 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
             d[j] = ok ? 1e10f : -1.0f;  // -1 marks a slot beyond N: never a maximum, never updated
         }
         int far = (int)start[b];
-        u64* gb = gran + (size_t)b * npoint * G;
-
-        for (int i = 0; i < npoint; ++i) {
-            far = __builtin_amdgcn_readfirstlane(far);
+        float cx, cy, cz;
+        {
             const float* c = p + (int64_t)far * sn;
-            const float cx = c[0], cy = c[sc], cz = c[2 * sc];
+            cx = c[0];
+            cy = c[sc];
+            cz = c[2 * sc];
+        }
+        u64* gb = gran + (size_t)b * npoint * 4 * G;
+
+#ifdef PN2_FPS_DIAG
+        unsigned long long st[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+        const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime(), ct0 = __builtin_amdgcn_s_memtime();
+#define STAMP(k)                                                  \
+    do {                                                          \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+        st[k] += t_ - tprev;                                      \
+        tprev = t_;                                               \
+    } while (0)
+#else
+#define STAMP(k)
+#endif
+        for (int i = 0; i < npoint; ++i) {
+#ifdef PN2_FPS_DIAG
+            tprev = __builtin_amdgcn_s_memtime();
+#endif
             if (g == 0 && tid == 0) {
                 out_idx[(size_t)b * npoint + i] = far;
                 if (out_xyz) {
@@ -70,7 +112,7 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
             }
             if (i == npoint - 1) break;
 
-            float bestd = -1.0f;
+            float bestd = -1.0f, bx = 0.f, by = 0.f, bz = 0.f;
             int bestj = 0;
 #pragma unroll
             for (int j = 0; j < PPT; ++j) {
@@ -80,46 +122,110 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
                 if (d[j] > bestd) {  // strict: the lowest index of this thread wins
                     bestd = d[j];
                     bestj = j;
+                    bx = x[j];
+                    by = y[j];
+                    bz = z[j];
                 }
             }
             const int bestn = base + bestj * T;
-            u64 key = bestd < 0.0f ? 0ull : (((u64)__float_as_uint(bestd)) << 32) | (u64)(0xFFFFFFFFu - (unsigned)bestn);
-            key = pn2::wave_max_u64(key);
+            const u64 mykey =
+                bestd < 0.0f ? 0ull : (((u64)__float_as_uint(bestd)) << 32) | (u64)(0xFFFFFFFFu - (unsigned)bestn);
+            const u64 wkey = pn2::wave_max_u64(mykey);
             const int buf = i & 1;
-            if (lane == 0) s_key[buf][wave] = key;
-            __syncthreads();
+            // the lane that owns the wave maximum (keys are unique unless all are 0) publishes key + coordinates
+            const u64 owners = __ballot(mykey == wkey);
+            if (lane == (int)__builtin_ctzll(owners)) {
+                s_key[buf][wave] = wkey;
+                s_xyz[buf][wave][0] = bx;
+                s_xyz[buf][wave][1] = by;
+                s_xyz[buf][wave][2] = bz;
+            }
+            STAMP(0);  // compute + wave reduce + LDS write
+            lds_barrier();
+            STAMP(1);  // barrier 1
             u64 k = s_key[buf][0];
+            int kw = 0;
 #pragma unroll
             for (int w = 1; w < NW; ++w) {
                 const u64 o = s_key[buf][w];
-                k = o > k ? o : k;
+                if (o > k) {
+                    k = o;
+                    kw = w;
+                }
             }
+            float nx = s_xyz[buf][kw][0], ny = s_xyz[buf][kw][1], nz = s_xyz[buf][kw][2];
             if (G > 1) {
                 if (wave == 0) {
-                    u64* slot = gb + (size_t)i * G;
-                    if (lane == 0) __hip_atomic_store(slot + g, k | kValid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    u64 v = kValid;
+                    u64* slot = gb + (size_t)i * 4 * G;
+                    const unsigned tag = (unsigned)(i + 1);
+                    if (lane < 4) {
+                        const float cxyz = lane == 1 ? nx : lane == 2 ? ny : nz;
+                        const u64 v = lane == 0 ? (k | kValid) : (((u64)tag) << 32) | (u64)__float_as_uint(cxyz);
+                        st_granule(slot + (size_t)lane * G + g, v);
+                    }
+                    STAMP(2);  // LDS scan + publish
+                    u64 v0 = kValid, v1 = 0, v2 = 0, v3 = 0;
                     if (lane < G) {
                         unsigned spins = 0;
+                        bool ok0 = false, ok1 = false, ok2 = false, ok3 = false;
                         for (;;) {
-                            v = __hip_atomic_load(slot + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if (v & kValid) break;
+                            if (!ok0) {
+                                v0 = ld_granule(slot + lane);
+                                ok0 = (v0 & kValid) != 0;
+                            }
+                            if (!ok1) {
+                                v1 = ld_granule(slot + G + lane);
+                                ok1 = (unsigned)(v1 >> 32) == tag;
+                            }
+                            if (!ok2) {
+                                v2 = ld_granule(slot + 2 * G + lane);
+                                ok2 = (unsigned)(v2 >> 32) == tag;
+                            }
+                            if (!ok3) {
+                                v3 = ld_granule(slot + 3 * G + lane);
+                                ok3 = (unsigned)(v3 >> 32) == tag;
+                            }
+                            if (ok0 && ok1 && ok2 && ok3) break;
                             if (++spins > kSpinLimit) {  // a member never arrived: flag it and let the grid drain
                                 atomicOr(err, 1u);
-                                v = kValid;
+                                v0 = kValid;
                                 break;
                             }
                             __builtin_amdgcn_s_sleep(1);
                         }
                     }
-                    v = pn2::wave_max_u64(v & ~kValid);
-                    if (lane == 0) s_win[buf] = v;
+                    STAMP(3);  // poll
+                    const u64 mine = v0 & ~kValid;
+                    const u64 best = pn2::wave_max_u64(mine);
+                    const u64 own = __ballot(lane < G && mine == best);
+                    if (lane == (int)__builtin_ctzll(own)) {
+                        s_win[buf] = best;
+                        s_wxyz[buf][0] = __uint_as_float((unsigned)v1);
+                        s_wxyz[buf][1] = __uint_as_float((unsigned)v2);
+                        s_wxyz[buf][2] = __uint_as_float((unsigned)v3);
+                    }
                 }
-                __syncthreads();
+                STAMP(4);  // group reduce + LDS write
+                lds_barrier();
+                STAMP(5);  // barrier 2
                 k = s_win[buf];
+                nx = s_wxyz[buf][0];
+                ny = s_wxyz[buf][1];
+                nz = s_wxyz[buf][2];
             }
             far = (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull));
+            cx = nx;
+            cy = ny;
+            cz = nz;
         }
+#ifdef PN2_FPS_DIAG
+        if (tid == 0 && g == 0 && b == 0) {
+            unsigned long long* dbg = (unsigned long long*)err + 2;   // workspace bytes 16.. (diag builds reserve 256)
+            for (int k = 0; k < 6; ++k) dbg[k] = st[k];
+            dbg[6] = __builtin_amdgcn_s_memtime() - ct0;
+            dbg[7] = __builtin_amdgcn_s_memrealtime() - rt0;
+        }
+#endif
         __syncthreads();  // LDS slots are reused by the next cloud of this group
     }
 }
@@ -130,11 +236,15 @@ struct Config {
 };
 
 // Pick (PPT, T, G): G members share one cloud; at most 256 workgroups so that every member is resident.
+// PN2_FPS_CFG="ppt,t" (tuning aid) pins the candidate.
 Config pick(int B, int N) {
-    static const int cand[][2] = {{1, 256}, {2, 256}, {4, 256}, {8, 256}, {4, 1024}, {8, 1024}, {16, 512}, {32, 512}};
+    static const int cand[][2] = {{1, 256}, {2, 256}, {4, 256}, {8, 256}, {16, 256}, {4, 1024}, {8, 1024}, {16, 512}, {32, 512}};
+    int force_p = 0, force_t = 0;
+    if (const char* e = getenv("PN2_FPS_CFG")) sscanf(e, "%d,%d", &force_p, &force_t);
     Config best{0, 0, 0, 0, 1e300};
     for (auto& c : cand) {
         const int ppt = c[0], t = c[1];
+        if (force_p && (ppt != force_p || t != force_t)) continue;
         const int G = pn2::ceil_div(N, (long long)ppt * t);
         if (G > kMaxG) continue;
         const int groups = B < (256 / G) ? B : (256 / G);
@@ -149,8 +259,8 @@ Config pick(int B, int N) {
 template <int PPT, int T>
 void launch(const Config& c, const float* xyz, int64_t sb, int64_t sn, int64_t sc, int B, int N, int npoint,
             const int64_t* start, int32_t* out_idx, float* out_xyz, u64* gran, unsigned* err, hipStream_t s) {
-    hipLaunchKernelGGL((fps_kernel<PPT, T>), dim3(c.groups * c.G), dim3(T), 0, s, xyz, sb, sn, sc, B, N, npoint, start,
-                       out_idx, out_xyz, gran, err, c.G, c.groups);
+    PN2_LAUNCH("fps", (double)B * (12.0 * N + 8.0 * npoint), 0, (fps_kernel<PPT, T>), dim3(c.groups * c.G), dim3(T), s, xyz, sb,
+               sn, sc, B, N, npoint, start, out_idx, out_xyz, gran, err, c.G, c.groups);
 }
 
 }  // namespace
@@ -159,8 +269,8 @@ extern "C" size_t pn2_fps_workspace_bytes(int B, int N, int npoint) {
     if (B <= 0 || N <= 0 || npoint <= 0) return 0;
     const Config c = pick(B, N);
     if (c.G == 0) return 0;
-    // [err word padded to 16 B][granules]
-    return 16 + (c.G > 1 ? (size_t)B * npoint * c.G * sizeof(u64) : 0);
+    // [err word padded to kHdr bytes][granules: 4 per (cloud, step, member)]
+    return kHdr + (c.G > 1 ? (size_t)B * npoint * 4 * c.G * sizeof(u64) : 0);
 }
 
 extern "C" int pn2_fps_f32(const float* xyz, int64_t sb, int64_t sn, int64_t sc, int B, int N, int npoint,
@@ -174,7 +284,7 @@ extern "C" int pn2_fps_f32(const float* xyz, int64_t sb, int64_t sn, int64_t sc,
     hipStream_t s = (hipStream_t)stream;
     PN2_HIP_CHECK(hipMemsetAsync(workspace, 0, need, s));
     unsigned* err = (unsigned*)workspace;
-    u64* gran = (u64*)((char*)workspace + 16);
+    u64* gran = (u64*)((char*)workspace + kHdr);
 #define PN2_FPS_CASE(P, T_)                                                                                  \
     if (c.ppt == P && c.t == T_) {                                                                           \
         launch<P, T_>(c, xyz, sb, sn, sc, B, N, npoint, start, out_idx, out_xyz, gran, err, s);              \
@@ -183,6 +293,7 @@ extern "C" int pn2_fps_f32(const float* xyz, int64_t sb, int64_t sn, int64_t sc,
     PN2_FPS_CASE(2, 256)
     PN2_FPS_CASE(4, 256)
     PN2_FPS_CASE(8, 256)
+    PN2_FPS_CASE(16, 256)
     PN2_FPS_CASE(4, 1024)
     PN2_FPS_CASE(8, 1024)
     PN2_FPS_CASE(16, 512)

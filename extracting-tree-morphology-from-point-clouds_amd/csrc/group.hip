@@ -84,8 +84,8 @@ extern "C" int pn2_group_f32(const float* xyz, int64_t sb, int64_t sn, int64_t s
     if (!xyz || !new_xyz || !idx || !out || B <= 0 || N <= 0 || S <= 0 || K <= 0 || D < 0 || (D > 0 && !feats))
         return PN2_E_BADARG;
     const long long total = (long long)B * S * K * (3 + D);
-    hipLaunchKernelGGL(group_kernel, dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream, xyz, sb, sn, sc, new_xyz,
-                       feats, fb, fn, fc, idx, B, N, S, K, D, xyz_last, out, total);
+    PN2_LAUNCH("group", 8.0 * total + 4.0 * B * S * K, 0, group_kernel, dim3(grid_for(total)), dim3(kBlock), (hipStream_t)stream,
+               xyz, sb, sn, sc, new_xyz, feats, fb, fn, fc, idx, B, N, S, K, D, xyz_last, out, total);
     PN2_LAUNCH_CHECK();
     return 0;
 }
@@ -96,8 +96,8 @@ extern "C" int pn2_group_grad_f32(const float* dout, const int32_t* idx, int B, 
     hipStream_t s = (hipStream_t)stream;
     PN2_HIP_CHECK(hipMemsetAsync(dfeats, 0, (size_t)B * N * D * sizeof(float), s));
     const long long total = (long long)B * S * K * D;
-    hipLaunchKernelGGL(group_grad_kernel, dim3(grid_for(total)), dim3(kBlock), 0, s, dout, idx, B, N, S, K, D, xyz_last,
-                       dfeats, total);
+    PN2_LAUNCH("group_grad", 8.0 * total + 4.0 * B * S * K + 4.0 * B * N * D, 0, group_grad_kernel, dim3(grid_for(total)),
+               dim3(kBlock), s, dout, idx, B, N, S, K, D, xyz_last, dfeats, total);
     PN2_LAUNCH_CHECK();
     return 0;
 }
@@ -106,8 +106,8 @@ extern "C" int pn2_gather_f32(const float* points, int64_t pb, int64_t pn, int64
                               int N, int S, int C, float* out, void* stream) {
     if (!points || !idx || !out || B <= 0 || N <= 0 || S <= 0 || C <= 0) return PN2_E_BADARG;
     const long long total = (long long)B * S * C;
-    hipLaunchKernelGGL(gather_kernel, dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream, points, pb, pn, pc, idx,
-                       B, N, S, C, out, total);
+    PN2_LAUNCH("gather", 8.0 * total + 4.0 * B * S, 0, gather_kernel, dim3(grid_for(total)), dim3(kBlock), (hipStream_t)stream,
+               points, pb, pn, pc, idx, B, N, S, C, out, total);
     PN2_LAUNCH_CHECK();
     return 0;
 }
@@ -118,7 +118,8 @@ extern "C" int pn2_gather_grad_f32(const float* dout, const int32_t* idx, int B,
     hipStream_t s = (hipStream_t)stream;
     PN2_HIP_CHECK(hipMemsetAsync(dpoints, 0, (size_t)B * N * C * sizeof(float), s));
     const long long total = (long long)B * S * C;
-    hipLaunchKernelGGL(gather_grad_kernel, dim3(grid_for(total)), dim3(kBlock), 0, s, dout, idx, B, N, S, C, dpoints, total);
+    PN2_LAUNCH("gather_grad", 8.0 * total + 4.0 * B * S + 4.0 * B * N * C, 0, gather_grad_kernel, dim3(grid_for(total)),
+               dim3(kBlock), s, dout, idx, B, N, S, C, dpoints, total);
     PN2_LAUNCH_CHECK();
     return 0;
 }

@@ -530,7 +530,10 @@ int launch_gemm(GemmArgs& g, int nsplit, hipStream_t s) {
     g.vecA = vec_ok(g.A);
     g.vecB = vec_ok(g.B);
     dim3 grid(pn2::ceil_div(g.M, BM), pn2::ceil_div(g.N, BN), nsplit);
-    hipLaunchKernelGGL((gemm_kernel<A_T, A_KIND, B_T, B_KIND, EPI>), grid, dim3(NT), 0, s, g);
+    const char* name = EPI == EPI_FWD ? "gemm_fwd" : EPI == EPI_STORE ? "gemm_dgrad" : "gemm_wgrad";
+    const double mk = (double)g.M * g.K * (A_KIND == TR_DY ? 2 : 1), kn = (double)g.K * g.N * (B_KIND == TR_DY ? 2 : 1);
+    const double bytes = 4.0 * (mk + kn + (double)g.M * g.N * (EPI == EPI_SLAB ? nsplit : 1));
+    PN2_LAUNCH(name, bytes, 2.0 * g.M * g.N * g.K, (gemm_kernel<A_T, A_KIND, B_T, B_KIND, EPI>), grid, dim3(NT), s, g);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
@@ -592,12 +595,13 @@ extern "C" int pn2_mlp_chain_fwd_f32(const float* x, int64_t ldx, int rows, cons
         if (st) return st;
         if (L.has_bn) {
             if (training) {
-                hipLaunchKernelGGL(bn_finalize_kernel, dim3(L.cout), dim3(256), 0, s, (const float*)workspace, rows, L.cout,
-                                   L.gamma, L.beta, L.running_mean, L.running_var, L.eps, L.momentum, L.stats);
+                PN2_LAUNCH("bn_finalize", 8.0 * pn2::ceil_div(rows, 64) * L.cout, 0, bn_finalize_kernel, dim3(L.cout), dim3(256), s,
+                           (const float*)workspace, rows, L.cout, L.gamma, L.beta, L.running_mean, L.running_var, L.eps,
+                           L.momentum, L.stats);
             } else {
                 if (!L.running_mean || !L.running_var) return PN2_E_BADARG;
-                hipLaunchKernelGGL(bn_eval_coef_kernel, dim3(pn2::ceil_div(L.cout, 256)), dim3(256), 0, s, L.cout, L.gamma,
-                                   L.beta, L.running_mean, L.running_var, L.eps, L.stats);
+                PN2_LAUNCH("bn_eval_coef", 36.0 * L.cout, 0, bn_eval_coef_kernel, dim3(pn2::ceil_div(L.cout, 256)), dim3(256), s,
+                           L.cout, L.gamma, L.beta, L.running_mean, L.running_var, L.eps, L.stats);
             }
             PN2_LAUNCH_CHECK();
             in = Act{y, L.cout, L.stats, L.relu};
@@ -610,11 +614,12 @@ extern "C" int pn2_mlp_chain_fwd_f32(const float* x, int64_t ldx, int rows, cons
             if (!L.has_bn || C % 4) return PN2_E_BADARG;
             if (pool_k > 1) {
                 const long long groups = rows / pool_k;
-                hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(grid1d(groups * C)), dim3(256), 0, s, (const float*)y, groups,
-                                   pool_k, C, (const float*)L.stats, L.relu, out, pool_arg);
+                PN2_LAUNCH("bn_relu_maxpool", 4.0 * rows * C + 8.0 * groups * C, 0, bn_relu_maxpool_kernel,
+                           dim3(grid1d(groups * C)), dim3(256), s, (const float*)y, groups, pool_k, C, (const float*)L.stats,
+                           L.relu, out, pool_arg);
             } else {
-                hipLaunchKernelGGL(bn_relu_apply_kernel, dim3(grid1d((long long)rows * C / 4)), dim3(256), 0, s,
-                                   (const float*)y, (long long)rows * C / 4, C, (const float*)L.stats, L.relu, out);
+                PN2_LAUNCH("bn_relu_apply", 8.0 * rows * C, 0, bn_relu_apply_kernel, dim3(grid1d((long long)rows * C / 4)),
+                           dim3(256), s, (const float*)y, (long long)rows * C / 4, C, (const float*)L.stats, L.relu, out);
             }
             PN2_LAUNCH_CHECK();
         }
@@ -638,8 +643,9 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
     if (pool_k > 1) {
         if (!pool_arg) return PN2_E_BADARG;
         const int C = layers[nlayers - 1].cout;
-        hipLaunchKernelGGL(maxpool_scatter_kernel, dim3(grid1d((long long)rows * C)), dim3(256), 0, s, dout, pool_arg,
-                           (long long)(rows / pool_k), pool_k, C, bufs[which]);
+        PN2_LAUNCH("maxpool_scatter", 4.0 * rows * C + 8.0 * (rows / pool_k) * C, 0, maxpool_scatter_kernel,
+                   dim3(grid1d((long long)rows * C)), dim3(256), s, dout, pool_arg, (long long)(rows / pool_k), pool_k, C,
+                   bufs[which]);
         PN2_LAUNCH_CHECK();
         dz = bufs[which];
         which ^= 1;
@@ -651,16 +657,16 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
         // ---- BatchNorm backward reductions -> coefficients a, b and dgamma, dbeta
         if (L.has_bn) {
             const int nblk = pn2::ceil_div(rows, RB);
-            hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, s, dz, lddz, y, (long long)L.cout, rows, L.cout,
-                               (const float*)L.stats, L.relu, ws);
-            hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(L.cout), dim3(256), 0, s, (const float*)ws, nblk, rows, L.cout,
-                               L.stats, L.dgamma, L.dbeta);
+            PN2_LAUNCH("bn_bwd_reduce", 8.0 * rows * L.cout, 0, bn_bwd_reduce_kernel, dim3(nblk), dim3(256), s, dz, lddz, y,
+                       (long long)L.cout, rows, L.cout, (const float*)L.stats, L.relu, ws);
+            PN2_LAUNCH("bn_bwd_finalize", 8.0 * nblk * L.cout, 0, bn_bwd_finalize_kernel, dim3(L.cout), dim3(256), s,
+                       (const float*)ws, nblk, rows, L.cout, L.stats, L.dgamma, L.dbeta);
             PN2_LAUNCH_CHECK();
         } else if (L.dbias) {
             const int nblk = pn2::ceil_div(rows, CS_ROWS);
-            hipLaunchKernelGGL(colsum_kernel, dim3(nblk), dim3(256), 0, s, dz, lddz, rows, L.cout, ws);
-            hipLaunchKernelGGL(colsum_finalize_kernel, dim3(pn2::ceil_div(L.cout, 64)), dim3(64), 0, s, (const float*)ws, nblk,
-                               L.cout, L.dbias);
+            PN2_LAUNCH("colsum", 4.0 * rows * L.cout, 0, colsum_kernel, dim3(nblk), dim3(256), s, dz, lddz, rows, L.cout, ws);
+            PN2_LAUNCH("colsum_finalize", 4.0 * nblk * L.cout, 0, colsum_finalize_kernel, dim3(pn2::ceil_div(L.cout, 64)),
+                       dim3(64), s, (const float*)ws, nblk, L.cout, L.dbias);
             PN2_LAUNCH_CHECK();
         }
         // dY operand (through BatchNorm+ReLU backward when the layer has one)
@@ -700,8 +706,9 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
                 st = in.coef ? launch_gemm<false, TR_PLAIN, false, TR_BNRELU, EPI_SLAB>(g, nsplit, s)
                              : launch_gemm<false, TR_PLAIN, false, TR_PLAIN, EPI_SLAB>(g, nsplit, s);
             if (st) return st;
-            hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid1d((long long)L.cout * L.cin)), dim3(256), 0, s, (const float*)ws,
-                               nsplit, (long long)L.cout * L.cin, L.dweight);
+            PN2_LAUNCH("slab_reduce", 4.0 * (nsplit + 2) * L.cout * L.cin, 0, slab_reduce_kernel,
+                       dim3(grid1d((long long)L.cout * L.cin)), dim3(256), s, (const float*)ws, nsplit,
+                       (long long)L.cout * L.cin, L.dweight);
             PN2_LAUNCH_CHECK();
         }
         // ---- dgrad: dX[rows][cin] = dY W

@@ -15,6 +15,13 @@
         if (e_ != hipSuccess) return (int)e_;   \
     } while (0)
 
+// Launch KERNEL (parenthesise template-ids) under a profiling scope carrying the launch's algorithmic bytes/flops.
+#define PN2_LAUNCH(NAME, BYTES, FLOPS, KERNEL, GRID, BLOCK, STREAM, ...)                 \
+    do {                                                                                 \
+        pn2::prof::Scope sc_(NAME, STREAM, (double)(BYTES), (double)(FLOPS));             \
+        hipLaunchKernelGGL(KERNEL, GRID, BLOCK, 0, STREAM, __VA_ARGS__);                  \
+    } while (0)
+
 #define PN2_HIP_CHECK(expr)                     \
     do {                                        \
         hipError_t e_ = (expr);                 \
@@ -22,6 +29,21 @@
     } while (0)
 
 namespace pn2 {
+
+namespace prof {
+extern bool g_enabled;
+// RAII bracket around one kernel launch (see prof.hip); a no-op unless profiling is enabled.
+class Scope {
+   public:
+    Scope(const char* name, hipStream_t s, double bytes, double flops);
+    ~Scope();
+
+   private:
+    bool active_;
+    hipStream_t s_;
+    size_t idx_ = 0;
+};
+}  // namespace prof
 
 constexpr int kWave = 64;
 
@@ -49,13 +71,27 @@ __device__ __forceinline__ unsigned long long lanemask_lt() {
     return (1ull << (threadIdx.x & 63)) - 1ull;
 }
 
+// Wavefront max of an unsigned 64-bit key, result in every lane.  DPP row shifts / row broadcasts (full-rate
+// VALU, ~10 cycles a step) instead of __shfl_xor, which lowers to ds_bpermute through the LDS crossbar
+// (~100+ cycles a step in a dependent chain -- it was 2/3 of an FPS step).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_max_step(unsigned long long v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, ROW_MASK, 0xF, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, ROW_MASK, 0xF, false);
+    const unsigned long long o = ((unsigned long long)hi << 32) | lo;   // lanes without a source read 0
+    return o > v ? o : v;
+}
+
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        unsigned long long o = __shfl_xor(v, off, 64);
-        v = o > v ? o : v;
-    }
-    return v;
+    v = dpp_max_step<0x111, 0xF>(v);  // row_shr:1
+    v = dpp_max_step<0x112, 0xF>(v);  // row_shr:2
+    v = dpp_max_step<0x114, 0xF>(v);  // row_shr:4
+    v = dpp_max_step<0x118, 0xF>(v);  // row_shr:8   -> lane 15 of each row holds the row max
+    v = dpp_max_step<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
+    v = dpp_max_step<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave max
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
+    return ((unsigned long long)hi << 32) | lo;
 }
 
 inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -168,8 +168,8 @@ extern "C" int pn2_three_nn_f32(const float* xyz1, int64_t ab, int64_t an, int64
                                 int64_t bn, int64_t bc, int B, int N, int S, int32_t* out_idx, float* out_w,
                                 float* out_dist, void* stream) {
     if (!xyz1 || !xyz2 || !out_idx || !out_w || B <= 0 || N <= 0 || S < 3 || B > 65535) return PN2_E_BADARG;
-    hipLaunchKernelGGL(three_nn_kernel, dim3(pn2::ceil_div(N, kBlock), B), dim3(kBlock), 0, (hipStream_t)stream, xyz1, ab,
-                       an, ac, xyz2, bb, bn, bc, N, S, out_idx, out_w, out_dist);
+    PN2_LAUNCH("three_nn", (double)B * (12.0 * N + 12.0 * S + 36.0 * N), 0, three_nn_kernel, dim3(pn2::ceil_div(N, kBlock), B),
+               dim3(kBlock), (hipStream_t)stream, xyz1, ab, an, ac, xyz2, bb, bn, bc, N, S, out_idx, out_w, out_dist);
     PN2_LAUNCH_CHECK();
     return 0;
 }
@@ -178,8 +178,8 @@ extern "C" int pn2_square_distance_f32(const float* src, int64_t ab, int64_t an,
                                        int64_t bn, int64_t bc, int B, int N, int M, float* out, void* stream) {
     if (!src || !dst || !out || B <= 0 || N <= 0 || M <= 0) return PN2_E_BADARG;
     const long long total = (long long)B * N * M;
-    hipLaunchKernelGGL(square_distance_kernel, dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream, src, ab, an, ac,
-                       dst, bb, bn, bc, N, M, out, total);
+    PN2_LAUNCH("square_distance", 4.0 * total + 12.0 * B * (N + M), 0, square_distance_kernel, dim3(grid_for(total)),
+               dim3(kBlock), (hipStream_t)stream, src, ab, an, ac, dst, bb, bn, bc, N, M, out, total);
     PN2_LAUNCH_CHECK();
     return 0;
 }
@@ -192,14 +192,15 @@ extern "C" int pn2_three_interpolate_f32(const float* points2, int64_t pb, int64
     const bool vec = pc == 1 && D % 4 == 0 && pn % 4 == 0 && pb % 4 == 0 && out_stride % 4 == 0 && out_offset % 4 == 0 &&
                      ((uintptr_t)points2 % 16 == 0) && ((uintptr_t)out % 16 == 0);
     hipStream_t s = (hipStream_t)stream;
+    const double ti_bytes = (double)B * N * (36.0 + 4.0 * D) + 4.0 * B * S * D;
     if (vec) {
         const long long total = (long long)B * N * (D / 4);
-        hipLaunchKernelGGL((three_interpolate_kernel<4>), dim3(grid_for(total)), dim3(kBlock), 0, s, points2, pb, pn, pc, idx,
-                           w, N, D, out, out_stride, out_offset, total);
+        PN2_LAUNCH("three_interpolate", ti_bytes, 0, (three_interpolate_kernel<4>), dim3(grid_for(total)), dim3(kBlock), s,
+                   points2, pb, pn, pc, idx, w, N, D, out, out_stride, out_offset, total);
     } else {
         const long long total = (long long)B * N * D;
-        hipLaunchKernelGGL((three_interpolate_kernel<1>), dim3(grid_for(total)), dim3(kBlock), 0, s, points2, pb, pn, pc, idx,
-                           w, N, D, out, out_stride, out_offset, total);
+        PN2_LAUNCH("three_interpolate", ti_bytes, 0, (three_interpolate_kernel<1>), dim3(grid_for(total)), dim3(kBlock), s,
+                   points2, pb, pn, pc, idx, w, N, D, out, out_stride, out_offset, total);
     }
     PN2_LAUNCH_CHECK();
     return 0;
@@ -213,8 +214,8 @@ extern "C" int pn2_three_interpolate_grad_f32(const float* dout, int64_t out_str
     hipStream_t s = (hipStream_t)stream;
     PN2_HIP_CHECK(hipMemsetAsync(dpoints2, 0, (size_t)B * S * D * sizeof(float), s));
     const long long total = (long long)B * N * D;
-    hipLaunchKernelGGL(three_interpolate_grad_kernel, dim3(grid_for(total)), dim3(kBlock), 0, s, dout, out_stride,
-                       out_offset, idx, w, N, S, D, dpoints2, total);
+    PN2_LAUNCH("three_interpolate_grad", (double)B * N * (36.0 + 4.0 * D) + 4.0 * B * S * D, 0, three_interpolate_grad_kernel,
+               dim3(grid_for(total)), dim3(kBlock), s, dout, out_stride, out_offset, idx, w, N, S, D, dpoints2, total);
     PN2_LAUNCH_CHECK();
     return 0;
 }

@@ -156,6 +156,16 @@ int pn2_mlp_chain_bwd_f32(const float *x, int64_t ldx, int rows, const pn2_mlp_l
                           float *scratch_a, float *scratch_b, void *workspace, size_t workspace_bytes,
                           void *stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Measurement hook (bench.py): with profiling enabled every kernel launch of the library is bracketed by two
+ * HIP events on its launch stream.  pn2_prof_collect synchronises on them, aggregates by (kernel name,
+ * algorithmic bytes, flops) of a launch, writes NUL-separated names and per-group totals, clears the records and
+ * returns the number of groups.  Not meant to be left on in production (it creates two events per launch).
+ */
+void pn2_prof_enable(int on);
+int pn2_prof_collect(char *names_buf, size_t names_cap, double *total_ms, long long *calls, double *bytes,
+                     double *flops, int max_groups);
+
 #ifdef __cplusplus
 }
 #endif
