@@ -24,7 +24,7 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32, LD = 132, NT = 256;
+constexpr int BK = 32, NT = 256;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 enum { TR_PLAIN = 0, TR_BNRELU = 1, TR_DY = 2 };
@@ -42,86 +42,103 @@ struct Operand {
     int relu;
 };
 
-template <int KIND>
-__device__ __forceinline__ float xform(const Operand& o, float v, float y, int ch) {
-    if (KIND == TR_PLAIN) return v;
-    const float mean = o.coef[ST_MEAN * o.cstride + ch];
-    const float scale = o.coef[ST_SCALE * o.cstride + ch];
-    const float beta = o.coef[ST_BETA * o.cstride + ch];
-    if (KIND == TR_BNRELU) {
-        const float t = __builtin_fmaf(v - mean, scale, beta);
-        return o.relu ? fmaxf(t, 0.0f) : t;
+// Branch-free tile loads: the address is clamped into the matrix and the value masked afterwards, so that all of
+// a thread's loads for a K-tile issue back to back and are waited for once (a branch per load made the compiler
+// wait for each load separately: 8-12 dependent memory round trips per K-tile).
+template <bool VEC>
+__device__ __forceinline__ float4 ld4(const float* base, long long ld, int r, int c, int nrows, int ncols) {
+    const int rc = r < nrows ? r : nrows - 1;
+    if (VEC) {  // ncols % 4 == 0 and c % 4 == 0: c < ncols implies c + 3 < ncols
+        const int cc = c < ncols ? c : ncols - 4;
+        return *(const float4*)(base + (long long)rc * ld + cc);
     }
-    // TR_DY
-    const float t = __builtin_fmaf(y - mean, scale, beta);
-    const float dz = (!o.relu || t > 0.0f) ? v : 0.0f;
-    const float a = o.coef[ST_A * o.cstride + ch], b = o.coef[ST_B * o.cstride + ch];
-    return scale * (dz - a - (y - mean) * b);
-}
-
-__device__ __forceinline__ float4 load4(const float* base, long long ld, int r, int c, int nrows, int ncols, bool vec) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r >= nrows || c >= ncols) return v;
-    const float* p = base + (long long)r * ld + c;
-    if (vec && c + 3 < ncols) return *(const float4*)p;
-    v.x = p[0];
-    if (c + 1 < ncols) v.y = p[1];
-    if (c + 2 < ncols) v.z = p[2];
-    if (c + 3 < ncols) v.w = p[3];
+    const float* p = base + (long long)rc * ld;
+    const int last = ncols - 1;
+    float4 v;
+    v.x = p[c < last ? c : last];
+    v.y = p[c + 1 < last ? c + 1 : last];
+    v.z = p[c + 2 < last ? c + 2 : last];
+    v.w = p[c + 3 < last ? c + 3 : last];
     return v;
 }
 
-// One operand's staging state: 4 float4 (+4 for the second source) per thread per K-tile.
-template <bool T_LAYOUT, int KIND>
+// One operand's staging state for a TILE x 32 (T layout: global [outer][k]) or 32 x TILE (D layout: global
+// [k][outer]) tile: TILE/32 float4 per thread (+ as many for the second source) and the BatchNorm coefficients
+// of the thread's 4 channels in registers.  The channel is always the contiguous global index: k for the T
+// layout (reloaded per K-tile), the outer index for the D layout (loaded once).
+template <bool T_LAYOUT, int KIND, int TILE, bool VEC>
 struct Stager {
-    float4 v[4], y[4];
-    // T layout: global [outer][k]; thread -> (kq = t & 7, o_sub = t >> 3), pass p: outer = o0 + 32 p + o_sub
-    // D layout: global [k][outer]; thread -> (oq = t & 31, k_sub = t >> 5), pass p: k = k0 + 8 p + k_sub
-    __device__ __forceinline__ void fetch(const Operand& o, int o0, int k0, bool vec) {
-        const int t = threadIdx.x;
+    static constexpr int NP = TILE / 32;
+    static constexpr int OQ = TILE / 4;      // D layout: threads per k-row
+    static constexpr int KPP = NT / OQ;      // D layout: k-rows per pass
+    static constexpr int LD = TILE + 4;
+    float4 v[NP], y[NP];
+    float cm[4], cs[4], cb[4], ca[4], cq[4];
+
+    __device__ __forceinline__ int chan0(int o0, int k0) const {
+        return T_LAYOUT ? k0 + 4 * ((int)threadIdx.x & 7) : o0 + 4 * ((int)threadIdx.x % OQ);
+    }
+    __device__ __forceinline__ int row_of(int p, int o0, int k0) const {
+        return T_LAYOUT ? o0 + 32 * p + ((int)threadIdx.x >> 3) : k0 + KPP * p + ((int)threadIdx.x / OQ);
+    }
+    __device__ __forceinline__ void load_coefs(const Operand& o, int c0) {
+        if (KIND == TR_PLAIN) return;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            int r, c;
-            if (T_LAYOUT) {
-                r = o0 + 32 * p + (t >> 3);
-                c = k0 + 4 * (t & 7);
-            } else {
-                r = k0 + 8 * p + (t >> 5);
-                c = o0 + 4 * (t & 31);
+        for (int j = 0; j < 4; ++j) {
+            const int ch = c0 + j < o.cols ? c0 + j : o.cols - 1;
+            cm[j] = o.coef[ST_MEAN * o.cstride + ch];
+            cs[j] = o.coef[ST_SCALE * o.cstride + ch];
+            cb[j] = o.coef[ST_BETA * o.cstride + ch];
+            if (KIND == TR_DY) {
+                ca[j] = o.coef[ST_A * o.cstride + ch];
+                cq[j] = o.coef[ST_B * o.cstride + ch];
             }
-            v[p] = load4(o.p, o.ld, r, c, o.rows, o.cols, vec);
-            if (KIND == TR_DY) y[p] = load4(o.q, o.ldq, r, c, o.rows, o.cols, vec);
         }
     }
+    __device__ __forceinline__ void prepare(const Operand& o, int o0) {
+        if (!T_LAYOUT) load_coefs(o, chan0(o0, 0));
+    }
+    __device__ __forceinline__ void fetch(const Operand& o, int o0, int k0) {
+        const int c = chan0(o0, k0);
+        if (T_LAYOUT) load_coefs(o, c);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int r = row_of(p, o0, k0);
+            v[p] = ld4<VEC>(o.p, o.ld, r, c, o.rows, o.cols);
+            if (KIND == TR_DY) y[p] = ld4<VEC>(o.q, o.ldq, r, c, o.rows, o.cols);
+        }
+    }
+    __device__ __forceinline__ float xf(float val, float yy, int j, int relu) const {
+        if (KIND == TR_PLAIN) return val;
+        if (KIND == TR_BNRELU) {
+            const float t = __builtin_fmaf(val - cm[j], cs[j], cb[j]);
+            return relu ? fmaxf(t, 0.0f) : t;
+        }
+        const float t = __builtin_fmaf(yy - cm[j], cs[j], cb[j]);
+        const float dz = (!relu || t > 0.0f) ? val : 0.0f;
+        return cs[j] * (dz - ca[j] - (yy - cm[j]) * cq[j]);
+    }
     __device__ __forceinline__ void commit(const Operand& o, float* S, int o0, int k0) {
-        const int t = threadIdx.x;
+        const int c = chan0(o0, k0);
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            int r, c;
-            if (T_LAYOUT) {
-                r = o0 + 32 * p + (t >> 3);
-                c = k0 + 4 * (t & 7);
-            } else {
-                r = k0 + 8 * p + (t >> 5);
-                c = o0 + 4 * (t & 31);
-            }
-            float e[4] = {v[p].x, v[p].y, v[p].z, v[p].w};
-            if (KIND != TR_PLAIN) {
-                const float yy[4] = {y[p].x, y[p].y, y[p].z, y[p].w};
+        for (int p = 0; p < NP; ++p) {
+            const int r = row_of(p, o0, k0);
+            const float e[4] = {v[p].x, v[p].y, v[p].z, v[p].w};
+            const float yy[4] = {y[p].x, y[p].y, y[p].z, y[p].w};
+            float w[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    // elements outside the matrix must stay exactly zero (they pad the contraction)
-                    const bool in = r < o.rows && c + j < o.cols;
-                    e[j] = in ? xform<KIND>(o, e[j], KIND == TR_DY ? yy[j] : 0.0f, c + j) : 0.0f;
-                }
+            for (int j = 0; j < 4; ++j) {
+                // elements outside the matrix must be exactly zero: they pad the contraction
+                const bool in = r < o.rows && c + j < o.cols;
+                w[j] = in ? xf(e[j], KIND == TR_DY ? yy[j] : 0.0f, j, o.relu) : 0.0f;
             }
             if (T_LAYOUT) {
-                const int m = 32 * p + (t >> 3), k = 4 * (t & 7);
+                const int m = 32 * p + ((int)threadIdx.x >> 3), k = 4 * ((int)threadIdx.x & 7);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) S[(k + j) * LD + m] = e[j];
+                for (int j = 0; j < 4; ++j) S[(k + j) * LD + m] = w[j];
             } else {
-                const int k = 8 * p + (t >> 5), m = 4 * (t & 31);
-                *(float4*)(S + k * LD + m) = make_float4(e[0], e[1], e[2], e[3]);
+                const int k = KPP * p + ((int)threadIdx.x / OQ), m = 4 * ((int)threadIdx.x % OQ);
+                *(float4*)(S + k * LD + m) = make_float4(w[0], w[1], w[2], w[3]);
             }
         }
     }
@@ -133,17 +150,25 @@ struct GemmArgs {
     float* C;             // EPI_FWD: Y [M][ldc]; EPI_STORE: [M][ldc]; EPI_SLAB: [split][M][ldc]
     long long ldc;
     const float* bias;    // EPI_FWD, may be null
-    float* partial;       // EPI_FWD + stats: [ceil(M/64)][2][N] (mean, M2) per 64-row chunk, or null
+    float* partial;       // EPI_FWD: [ceil(M/64)][2][N] (mean, M2) per 64-row chunk; EPI_STORE: (s1, s2); or null
     int k_per_split;      // EPI_SLAB: K range per blockIdx.z
-    int vecA, vecB;
+    // EPI_STORE with partial: the output is dZ of the PREVIOUS layer; its BatchNorm-backward column sums are taken
+    // here from the accumulators (needs that layer's Y and coefficient block)
+    const float* ey;
+    long long ldey;
+    const float* ecoef;
+    int erelu;
 };
 
-template <bool A_T, int A_KIND, bool B_T, int B_KIND, int EPI>
+// TILE = 128: four waves own 64 x 64 each (2 x 2 MFMA accumulators); TILE = 64: 32 x 32 each (one accumulator),
+// for problems too small to fill the chip with 128-tiles.
+template <bool A_T, int A_KIND, bool B_T, int B_KIND, int EPI, int TILE, bool VEC>
 __global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs g) {
+    constexpr int LD = TILE + 4, WT = TILE / 2, NI = WT / 32;
     __shared__ __attribute__((aligned(16))) float As[2][BK * LD];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK * LD];
 
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int m0 = blockIdx.x * TILE, n0 = blockIdx.y * TILE;
     int k_begin = 0, k_end = g.K;
     if (EPI == EPI_SLAB) {
         k_begin = blockIdx.z * g.k_per_split;
@@ -152,20 +177,22 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs g) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, half = lane >> 5;
 
-    f32x16 acc[2][2];
+    f32x16 acc[NI][NI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    Stager<A_T, A_KIND> sa;
-    Stager<B_T, B_KIND> sb;
+    Stager<A_T, A_KIND, TILE, VEC> sa;
+    Stager<B_T, B_KIND, TILE, VEC> sb;
+    sa.prepare(g.A, m0);
+    sb.prepare(g.B, n0);
     const int nk = (k_end - k_begin + BK - 1) / BK;
     if (nk > 0) {
-        sa.fetch(g.A, m0, k_begin, g.vecA);
-        sb.fetch(g.B, n0, k_begin, g.vecB);
+        sa.fetch(g.A, m0, k_begin);
+        sb.fetch(g.B, n0, k_begin);
         sa.commit(g.A, As[0], m0, k_begin);
         sb.commit(g.B, Bs[0], n0, k_begin);
     }
@@ -174,19 +201,24 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs g) {
         const int cur = kt & 1;
         const int knext = k_begin + (kt + 1) * BK;
         if (kt + 1 < nk) {
-            sa.fetch(g.A, m0, knext, g.vecA);
-            sb.fetch(g.B, n0, knext, g.vecB);
+            sa.fetch(g.A, m0, knext);
+            sb.fetch(g.B, n0, knext);
         }
-        const float* a = As[cur] + wm * 64 + l31;
-        const float* b = Bs[cur] + wn * 64 + l31;
+        const float* a = As[cur] + wm * WT + l31;
+        const float* b = Bs[cur] + wn * WT + l31;
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             const int ko = (kk + half) * LD;
-            const float a0 = a[ko], a1 = a[ko + 32], b0 = b[ko], b1 = b[ko + 32];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            float av[NI], bv[NI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                av[i] = a[ko + 32 * i];
+                bv[i] = b[ko + 32 * i];
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
         if (kt + 1 < nk) {
             sa.commit(g.A, As[cur ^ 1], m0, knext);
@@ -198,16 +230,16 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs g) {
     // ---- epilogue.  C/D layout of 32x32x2: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     float* C = g.C;
     if (EPI == EPI_SLAB) C += (long long)blockIdx.z * g.M * g.ldc;
-    const int rbase = m0 + wm * 64 + 4 * half;
+    const int rbase = m0 + wm * WT + 4 * half;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wn * 64 + 32 * j + l31;
+    for (int j = 0; j < NI; ++j) {
+        const int col = n0 + wn * WT + 32 * j + l31;
         const bool cok = col < g.N;
         const float bias = (EPI == EPI_FWD && g.bias && cok) ? g.bias[col] : 0.0f;
         float sum = 0.0f;
         int cnt = 0;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = rbase + 32 * i + (r & 3) + 8 * (r >> 2);
@@ -219,14 +251,15 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs g) {
                     ++cnt;
                 }
             }
+        // per-(row chunk of WT rows, column) partials; the other half-wave holds the other rows of the column
+        const long long chunk = (m0 + wm * WT) / WT;
         if (EPI == EPI_FWD && g.partial) {
-            // per-(64-row chunk, column) mean and M2; the other half-wave holds the other 32 rows of the column
             sum += __shfl_xor(sum, 32, 64);
             cnt += __shfl_xor(cnt, 32, 64);
             const float mean = cnt > 0 ? sum / (float)cnt : 0.0f;
             float m2 = 0.0f;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = rbase + 32 * i + (r & 3) + 8 * (r >> 2);
@@ -234,30 +267,54 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs g) {
                     if (row < g.M) m2 += d * d;
                 }
             m2 += __shfl_xor(m2, 32, 64);
-            if (half == 0 && cok && m0 + wm * 64 < g.M) {
-                const long long chunk = (m0 + wm * 64) / 64;
+            if (half == 0 && cok && m0 + wm * WT < g.M) {
                 g.partial[(chunk * 2 + 0) * g.N + col] = mean;
                 g.partial[(chunk * 2 + 1) * g.N + col] = m2;
+            }
+        }
+        if (EPI == EPI_STORE && g.partial) {
+            // BatchNorm-backward sums of the layer whose dZ this tile is: s1 = sum mask*dz, s2 = sum mask*dz*xhat
+            const int cc = cok ? col : 0;
+            const float mean = g.ecoef[ST_MEAN * g.N + cc], sc = g.ecoef[ST_SCALE * g.N + cc];
+            const float bt = g.ecoef[ST_BETA * g.N + cc], invstd = g.ecoef[ST_INVSTD * g.N + cc];
+            float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + 32 * i + (r & 3) + 8 * (r >> 2);
+                    const int rr = row < g.M ? row : g.M - 1;
+                    const float yy = g.ey[(long long)rr * g.ldey + cc];
+                    const float t = __builtin_fmaf(yy - mean, sc, bt);
+                    const float dzh = (row < g.M && (!g.erelu || t > 0.0f)) ? acc[i][j][r] : 0.0f;
+                    s1 += dzh;
+                    s2 += dzh * ((yy - mean) * invstd);
+                }
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (half == 0 && cok && m0 + wm * WT < g.M) {
+                g.partial[(chunk * 2 + 0) * g.N + col] = s1;
+                g.partial[(chunk * 2 + 1) * g.N + col] = s2;
             }
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------- BatchNorm: forward
-// One block per channel: merge the 64-row (mean, M2) partials in float64, write the coefficient block and
+// One block per channel: merge the CH-row (mean, M2) partials in float64, write the coefficient block and
 // update the running statistics exactly like nn.BatchNorm (biased variance for normalisation, unbiased for
 // running_var).
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int rows, int C,
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int rows, int CH, int C,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
                                                           float eps, float momentum, float* __restrict__ coef) {
     __shared__ double red[256];
     __shared__ double s_mean;
     const int c = blockIdx.x, t = threadIdx.x;
-    const int nchunk = (rows + 63) / 64;
+    const int nchunk = (rows + CH - 1) / CH;
     double acc = 0.0;
     for (int k = t; k < nchunk; k += 256) {
-        const int n = rows - k * 64 < 64 ? rows - k * 64 : 64;
+        const int n = rows - k * CH < CH ? rows - k * CH : CH;
         acc += (double)n * (double)partial[((long long)k * 2) * C + c];
     }
     red[t] = acc;
@@ -271,7 +328,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     const double mean = s_mean;
     acc = 0.0;
     for (int k = t; k < nchunk; k += 256) {
-        const int n = rows - k * 64 < 64 ? rows - k * 64 : 64;
+        const int n = rows - k * CH < CH ? rows - k * CH : CH;
         const double d = (double)partial[((long long)k * 2) * C + c] - mean;
         acc += (double)partial[((long long)k * 2 + 1) * C + c] + (double)n * d * d;
     }
@@ -376,43 +433,66 @@ __global__ __launch_bounds__(256) void maxpool_scatter_kernel(const float* __res
 }
 
 // ------------------------------------------------------------------------------------------ BatchNorm: backward
-// partial[blk][0][c] = sum_r dzhat, partial[blk][1][c] = sum_r dzhat * xhat over the block's 256 rows
-constexpr int RB = 256;
+// partial[blk][0][c] = sum_r dzhat, partial[blk][1][c] = sum_r dzhat * xhat over the block's RB rows.
+// Each thread owns 4 consecutive channels (16-byte loads of dz and y), row groups are combined through LDS.
+constexpr int RB = 64;
+template <bool VEC>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dz, long long lddz,
                                                             const float* __restrict__ y, long long ldy, int rows, int C,
                                                             const float* __restrict__ coef, int relu,
                                                             float* __restrict__ partial) {
-    __shared__ float red[2][256];
+    __shared__ float red[2][256][4];
     const int r0 = blockIdx.x * RB;
     const int r1 = r0 + RB < rows ? r0 + RB : rows;
-    // threads along channels: groups of `cw` columns, `rg` row groups
-    const int cw = C < 256 ? (C <= 32 ? 32 : C <= 64 ? 64 : C <= 128 ? 128 : 256) : 256;
-    const int rg = 256 / cw;
+    const int C4 = (C + 3) / 4;
+    const int cw = C4 < 256 ? (C4 <= 8 ? 8 : C4 <= 16 ? 16 : C4 <= 32 ? 32 : C4 <= 64 ? 64 : C4 <= 128 ? 128 : 256) : 256;
+    const int rg = 256 / cw;                       // row groups working in parallel
     const int tc = threadIdx.x % cw, tr = threadIdx.x / cw;
-    for (int c0 = 0; c0 < C; c0 += cw) {
-        const int c = c0 + tc;
-        float s1 = 0.f, s2 = 0.f;
+    for (int q0 = 0; q0 < C4; q0 += cw) {
+        const int c = 4 * (q0 + tc);
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
         if (c < C) {
-            const float mean = coef[ST_MEAN * C + c], sc = coef[ST_SCALE * C + c], bt = coef[ST_BETA * C + c];
-            const float invstd = coef[ST_INVSTD * C + c];
+            float mean[4], sc[4], bt[4], is[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int cc = c + j < C ? c + j : C - 1;
+                mean[j] = coef[ST_MEAN * C + cc];
+                sc[j] = coef[ST_SCALE * C + cc];
+                bt[j] = coef[ST_BETA * C + cc];
+                is[j] = coef[ST_INVSTD * C + cc];
+            }
             for (int r = r0 + tr; r < r1; r += rg) {
-                const float yy = y[(long long)r * ldy + c];
-                const float t = __builtin_fmaf(yy - mean, sc, bt);
-                const float g = (!relu || t > 0.f) ? dz[(long long)r * lddz + c] : 0.f;
-                s1 += g;
-                s2 += g * ((yy - mean) * invstd);
+                const float4 yv = ld4<VEC>(y, ldy, r, c, rows, C);
+                const float4 dv = ld4<VEC>(dz, lddz, r, c, rows, C);
+                const float yy[4] = {yv.x, yv.y, yv.z, yv.w}, dd[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float t = __builtin_fmaf(yy[j] - mean[j], sc[j], bt[j]);
+                    const float g = (!relu || t > 0.f) ? dd[j] : 0.f;
+                    s1[j] += g;
+                    s2[j] += g * ((yy[j] - mean[j]) * is[j]);
+                }
             }
         }
-        red[0][threadIdx.x] = s1;
-        red[1][threadIdx.x] = s2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            red[0][threadIdx.x][j] = s1[j];
+            red[1][threadIdx.x][j] = s2[j];
+        }
         __syncthreads();
         if (tr == 0 && c < C) {
-            for (int k = 1; k < rg; ++k) {
-                s1 += red[0][k * cw + tc];
-                s2 += red[1][k * cw + tc];
-            }
-            partial[((long long)blockIdx.x * 2 + 0) * C + c] = s1;
-            partial[((long long)blockIdx.x * 2 + 1) * C + c] = s2;
+            for (int k = 1; k < rg; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    s1[j] += red[0][k * cw + tc][j];
+                    s2[j] += red[1][k * cw + tc][j];
+                }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (c + j < C) {
+                    partial[((long long)blockIdx.x * 2 + 0) * C + c + j] = s1[j];
+                    partial[((long long)blockIdx.x * 2 + 1) * C + c + j] = s2[j];
+                }
         }
         __syncthreads();
     }
@@ -452,9 +532,13 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, int nsplit, long long mn,
                                                           float* __restrict__ out) {
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < mn; e += (long long)gridDim.x * 256) {
-        float s = 0.f;
-        for (int k = 0; k < nsplit; ++k) s += slab[(long long)k * mn + e];
-        out[e] += s;
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int k = 0;
+        for (; k + 8 <= nsplit; k += 8)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += slab[(long long)(k + u) * mn + e];
+        for (; k < nsplit; ++k) a[0] += slab[(long long)k * mn + e];
+        out[e] += ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     }
 }
 
@@ -525,20 +609,49 @@ Operand act_operand(const Act& a, int rows, int cols) {
     return o;
 }
 
-template <bool A_T, int A_KIND, bool B_T, int B_KIND, int EPI>
-int launch_gemm(GemmArgs& g, int nsplit, hipStream_t s) {
-    g.vecA = vec_ok(g.A);
-    g.vecB = vec_ok(g.B);
-    dim3 grid(pn2::ceil_div(g.M, BM), pn2::ceil_div(g.N, BN), nsplit);
+// Tile choice: 128-tiles unless they would leave most of the chip idle (deep levels have a few hundred rows).
+inline int pick_tile(int M, int N, int nsplit) {
+    if (M <= 64 || N <= 64) return 64;   // a narrow output (the 128 -> 2/3 head convs) wastes less of a 64-tile
+    const long long big = (long long)pn2::ceil_div(M, 128) * pn2::ceil_div(N, 128) * nsplit;
+    return big >= 96 ? 128 : 64;
+}
+
+template <bool A_T, int A_KIND, bool B_T, int B_KIND, int EPI, int TILE, bool VEC>
+int launch_gemm_tv(GemmArgs& g, int nsplit, hipStream_t s) {
+    dim3 grid(pn2::ceil_div(g.M, TILE), pn2::ceil_div(g.N, TILE), nsplit);
     const char* name = EPI == EPI_FWD ? "gemm_fwd" : EPI == EPI_STORE ? "gemm_dgrad" : "gemm_wgrad";
     const double mk = (double)g.M * g.K * (A_KIND == TR_DY ? 2 : 1), kn = (double)g.K * g.N * (B_KIND == TR_DY ? 2 : 1);
     const double bytes = 4.0 * (mk + kn + (double)g.M * g.N * (EPI == EPI_SLAB ? nsplit : 1));
-    PN2_LAUNCH(name, bytes, 2.0 * g.M * g.N * g.K, (gemm_kernel<A_T, A_KIND, B_T, B_KIND, EPI>), grid, dim3(NT), s, g);
+    PN2_LAUNCH(name, bytes, 2.0 * g.M * g.N * g.K, (gemm_kernel<A_T, A_KIND, B_T, B_KIND, EPI, TILE, VEC>), grid, dim3(NT), s, g);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
 
+template <bool A_T, int A_KIND, bool B_T, int B_KIND, int EPI>
+int launch_gemm(GemmArgs& g, int nsplit, int tile, hipStream_t s) {
+    const bool vec = vec_ok(g.A) && vec_ok(g.B);
+    if (tile == 128)
+        return vec ? launch_gemm_tv<A_T, A_KIND, B_T, B_KIND, EPI, 128, true>(g, nsplit, s)
+                   : launch_gemm_tv<A_T, A_KIND, B_T, B_KIND, EPI, 128, false>(g, nsplit, s);
+    return vec ? launch_gemm_tv<A_T, A_KIND, B_T, B_KIND, EPI, 64, true>(g, nsplit, s)
+               : launch_gemm_tv<A_T, A_KIND, B_T, B_KIND, EPI, 64, false>(g, nsplit, s);
+}
+
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct WgradPlan {
+    int tile, nsplit, kps;
+};
+
+// dW = dY^T X reduces over `rows`; the reduction is cut into nsplit row ranges (one slab each, summed in fixed order)
+WgradPlan plan_wgrad(int rows, int cout, int cin) {
+    const int tiles = pn2::ceil_div(cout, 128) * pn2::ceil_div(cin, 128);
+    int nsplit = 256 / tiles;
+    if (nsplit < 1) nsplit = 1;
+    const int kps = pn2::ceil_div(pn2::ceil_div(rows, nsplit), BK) * BK;
+    nsplit = pn2::ceil_div(rows, kps);
+    return WgradPlan{pick_tile(cout, cin, nsplit), nsplit, kps};
+}
 
 }  // namespace
 
@@ -548,18 +661,13 @@ extern "C" size_t pn2_mlp_workspace_bytes(int rows, const pn2_mlp_layer* layers,
     size_t need = 0;
     for (int i = 0; i < nlayers; ++i) {
         const size_t cin = layers[i].cin, cout = layers[i].cout;
-        const size_t fwd = (size_t)pn2::ceil_div(rows, 64) * 2 * cout * sizeof(float);      // stats partials
-        size_t bwd_red = (size_t)pn2::ceil_div(rows, RB) * 2 * cout * sizeof(float);         // s1/s2 partials
+        // per-row-chunk partials (forward stats, backward sums): chunks are >= 32 rows; channels up to max(cin, cout)
+        const size_t cmax = cin > cout ? cin : cout;
+        const size_t part = (size_t)pn2::ceil_div(rows, 32) * 2 * cmax * sizeof(float);
         const size_t cs = (size_t)pn2::ceil_div(rows, CS_ROWS) * cout * sizeof(float);         // bias column sums
-        bwd_red = bwd_red > cs ? bwd_red : cs;
-        // wgrad slabs: at most 256 row splits of one 128x128 tile grid
-        const size_t tiles = (size_t)pn2::ceil_div((int)cout, BM) * pn2::ceil_div((int)cin, BN);
-        size_t splits = 256 / tiles;
-        if (splits < 1) splits = 1;
-        const size_t maxs = (size_t)pn2::ceil_div(rows, BK);
-        if (splits > maxs) splits = maxs;
-        const size_t slab = splits * cout * cin * sizeof(float);
-        size_t m = fwd > bwd_red ? fwd : bwd_red;
+        const WgradPlan wp = plan_wgrad(rows, (int)cout, (int)cin);
+        const size_t slab = (size_t)wp.nsplit * cout * cin * sizeof(float);
+        size_t m = part > cs ? part : cs;
         m = m > slab ? m : slab;
         need = need > m ? need : m;
     }
@@ -590,13 +698,15 @@ extern "C" int pn2_mlp_chain_fwd_f32(const float* x, int64_t ldx, int rows, cons
         g.ldc = L.cout;
         g.bias = L.bias;
         g.partial = (L.has_bn && training) ? (float*)workspace : nullptr;
-        int st = in.coef ? launch_gemm<true, TR_BNRELU, true, TR_PLAIN, EPI_FWD>(g, 1, s)
-                         : launch_gemm<true, TR_PLAIN, true, TR_PLAIN, EPI_FWD>(g, 1, s);
+        const int tile = pick_tile(rows, L.cout, 1);
+        int st = in.coef ? launch_gemm<true, TR_BNRELU, true, TR_PLAIN, EPI_FWD>(g, 1, tile, s)
+                         : launch_gemm<true, TR_PLAIN, true, TR_PLAIN, EPI_FWD>(g, 1, tile, s);
         if (st) return st;
         if (L.has_bn) {
             if (training) {
-                PN2_LAUNCH("bn_finalize", 8.0 * pn2::ceil_div(rows, 64) * L.cout, 0, bn_finalize_kernel, dim3(L.cout), dim3(256), s,
-                           (const float*)workspace, rows, L.cout, L.gamma, L.beta, L.running_mean, L.running_var, L.eps,
+                const int ch = tile / 2;
+                PN2_LAUNCH("bn_finalize", 8.0 * pn2::ceil_div(rows, ch) * L.cout, 0, bn_finalize_kernel, dim3(L.cout), dim3(256),
+                           s, (const float*)workspace, rows, ch, L.cout, L.gamma, L.beta, L.running_mean, L.running_var, L.eps,
                            L.momentum, L.stats);
             } else {
                 if (!L.running_mean || !L.running_var) return PN2_E_BADARG;
@@ -650,15 +760,26 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
         dz = bufs[which];
         which ^= 1;
     }
+    int fused_chunk = 0;  // > 0: the BatchNorm-backward partials of the current layer are already in ws (chunk rows)
     for (int i = nlayers - 1; i >= 0; --i) {
         const pn2_mlp_layer& L = layers[i];
         const bool last = i == nlayers - 1;
         const float* y = (last && !L.has_bn && pool_k <= 1) ? nullptr : L.y;
         // ---- BatchNorm backward reductions -> coefficients a, b and dgamma, dbeta
         if (L.has_bn) {
-            const int nblk = pn2::ceil_div(rows, RB);
-            PN2_LAUNCH("bn_bwd_reduce", 8.0 * rows * L.cout, 0, bn_bwd_reduce_kernel, dim3(nblk), dim3(256), s, dz, lddz, y,
-                       (long long)L.cout, rows, L.cout, (const float*)L.stats, L.relu, ws);
+            int nblk;
+            if (fused_chunk) {
+                nblk = pn2::ceil_div(rows, fused_chunk);   // written by the dgrad epilogue of layer i + 1
+            } else {
+                nblk = pn2::ceil_div(rows, RB);
+                const bool vec = (L.cout % 4 == 0) && (lddz % 4 == 0) && aligned16(dz) && aligned16(y);
+                if (vec)
+                    PN2_LAUNCH("bn_bwd_reduce", 8.0 * rows * L.cout, 0, (bn_bwd_reduce_kernel<true>), dim3(nblk), dim3(256), s, dz,
+                               lddz, y, (long long)L.cout, rows, L.cout, (const float*)L.stats, L.relu, ws);
+                else
+                    PN2_LAUNCH("bn_bwd_reduce", 8.0 * rows * L.cout, 0, (bn_bwd_reduce_kernel<false>), dim3(nblk), dim3(256), s, dz,
+                               lddz, y, (long long)L.cout, rows, L.cout, (const float*)L.stats, L.relu, ws);
+            }
             PN2_LAUNCH("bn_bwd_finalize", 8.0 * nblk * L.cout, 0, bn_bwd_finalize_kernel, dim3(L.cout), dim3(256), s,
                        (const float*)ws, nblk, rows, L.cout, L.stats, L.dgamma, L.dbeta);
             PN2_LAUNCH_CHECK();
@@ -669,6 +790,7 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
                        dim3(64), s, (const float*)ws, nblk, L.cout, L.dbias);
             PN2_LAUNCH_CHECK();
         }
+        fused_chunk = 0;
         // dY operand (through BatchNorm+ReLU backward when the layer has one)
         Operand dy = plain(dz, lddz, rows, L.cout);
         if (L.has_bn) {
@@ -684,11 +806,7 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
                               layers[i - 1].relu};
         // ---- wgrad: dW[cout][cin] += dY^T X, reduction over rows split across blocks
         if (L.dweight) {
-            const int tiles = pn2::ceil_div(L.cout, BM) * pn2::ceil_div(L.cin, BN);
-            int nsplit = 256 / tiles;
-            if (nsplit < 1) nsplit = 1;
-            int kps = pn2::ceil_div(pn2::ceil_div(rows, nsplit), BK) * BK;
-            nsplit = pn2::ceil_div(rows, kps);
+            const WgradPlan wp = plan_wgrad(rows, L.cout, L.cin);
             GemmArgs g{};
             g.A = dy;                       // [rows = K][cout = M], direct layout
             g.B = act_operand(in, rows, L.cin);
@@ -697,21 +815,22 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
             g.K = rows;
             g.C = ws;
             g.ldc = L.cin;
-            g.k_per_split = kps;
+            g.k_per_split = wp.kps;
             int st;
             if (L.has_bn)
-                st = in.coef ? launch_gemm<false, TR_DY, false, TR_BNRELU, EPI_SLAB>(g, nsplit, s)
-                             : launch_gemm<false, TR_DY, false, TR_PLAIN, EPI_SLAB>(g, nsplit, s);
+                st = in.coef ? launch_gemm<false, TR_DY, false, TR_BNRELU, EPI_SLAB>(g, wp.nsplit, wp.tile, s)
+                             : launch_gemm<false, TR_DY, false, TR_PLAIN, EPI_SLAB>(g, wp.nsplit, wp.tile, s);
             else
-                st = in.coef ? launch_gemm<false, TR_PLAIN, false, TR_BNRELU, EPI_SLAB>(g, nsplit, s)
-                             : launch_gemm<false, TR_PLAIN, false, TR_PLAIN, EPI_SLAB>(g, nsplit, s);
+                st = in.coef ? launch_gemm<false, TR_PLAIN, false, TR_BNRELU, EPI_SLAB>(g, wp.nsplit, wp.tile, s)
+                             : launch_gemm<false, TR_PLAIN, false, TR_PLAIN, EPI_SLAB>(g, wp.nsplit, wp.tile, s);
             if (st) return st;
-            PN2_LAUNCH("slab_reduce", 4.0 * (nsplit + 2) * L.cout * L.cin, 0, slab_reduce_kernel,
-                       dim3(grid1d((long long)L.cout * L.cin)), dim3(256), s, (const float*)ws, nsplit,
+            PN2_LAUNCH("slab_reduce", 4.0 * (wp.nsplit + 2) * L.cout * L.cin, 0, slab_reduce_kernel,
+                       dim3(grid1d((long long)L.cout * L.cin)), dim3(256), s, (const float*)ws, wp.nsplit,
                        (long long)L.cout * L.cin, L.dweight);
             PN2_LAUNCH_CHECK();
         }
-        // ---- dgrad: dX[rows][cin] = dY W
+        // ---- dgrad: dX[rows][cin] = dY W; when the previous layer has a BatchNorm its backward column sums are
+        //      taken from the accumulators in the epilogue (no separate pass over dX and Y)
         const bool need_dx = i > 0 || dx != nullptr;
         if (need_dx) {
             float* target = i > 0 ? bufs[which] : dx;
@@ -724,8 +843,17 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
             g.K = L.cout;
             g.C = target;
             g.ldc = ldt;
-            int st = L.has_bn ? launch_gemm<true, TR_DY, false, TR_PLAIN, EPI_STORE>(g, 1, s)
-                              : launch_gemm<true, TR_PLAIN, false, TR_PLAIN, EPI_STORE>(g, 1, s);
+            const int tile = pick_tile(rows, L.cin, 1);
+            if (i > 0 && layers[i - 1].has_bn) {
+                g.partial = ws;
+                g.ey = layers[i - 1].y;
+                g.ldey = layers[i - 1].cout;
+                g.ecoef = layers[i - 1].stats;
+                g.erelu = layers[i - 1].relu;
+                fused_chunk = tile / 2;
+            }
+            int st = L.has_bn ? launch_gemm<true, TR_DY, false, TR_PLAIN, EPI_STORE>(g, 1, tile, s)
+                              : launch_gemm<true, TR_PLAIN, false, TR_PLAIN, EPI_STORE>(g, 1, tile, s);
             if (st) return st;
             dz = target;
             lddz = ldt;
