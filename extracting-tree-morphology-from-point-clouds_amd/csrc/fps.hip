@@ -143,17 +143,31 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
             STAMP(0);  // compute + wave reduce + LDS write
             lds_barrier();
             STAMP(1);  // barrier 1
-            u64 k = s_key[buf][0];
-            int kw = 0;
+            // workgroup winner: lane w reads wave w's candidate, one DPP reduction (instead of a 16-deep compare
+            // chain in every thread).  With G > 1 only the publishing wave needs it.
+            u64 k = 0;
+            float nx = 0.f, ny = 0.f, nz = 0.f;
+            if (G == 1 || wave == 0) {
+                int kw = 0;
+                if (NW <= 4) {
+                    k = s_key[buf][0];
 #pragma unroll
-            for (int w = 1; w < NW; ++w) {
-                const u64 o = s_key[buf][w];
-                if (o > k) {
-                    k = o;
-                    kw = w;
+                    for (int w = 1; w < NW; ++w) {
+                        const u64 o = s_key[buf][w];
+                        if (o > k) {
+                            k = o;
+                            kw = w;
+                        }
+                    }
+                } else {
+                    const u64 cand = lane < NW ? s_key[buf][lane] : 0ull;
+                    k = pn2::wave_max_u64(cand);
+                    kw = (int)__builtin_ctzll(__ballot(lane < NW && cand == k));
                 }
+                nx = s_xyz[buf][kw][0];
+                ny = s_xyz[buf][kw][1];
+                nz = s_xyz[buf][kw][2];
             }
-            float nx = s_xyz[buf][kw][0], ny = s_xyz[buf][kw][1], nz = s_xyz[buf][kw][2];
             if (G > 1) {
                 if (wave == 0) {
                     u64* slot = gb + (size_t)i * 4 * G;
@@ -167,25 +181,15 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
                     u64 v0 = kValid, v1 = 0, v2 = 0, v3 = 0;
                     if (lane < G) {
                         unsigned spins = 0;
-                        bool ok0 = false, ok1 = false, ok2 = false, ok3 = false;
                         for (;;) {
-                            if (!ok0) {
-                                v0 = ld_granule(slot + lane);
-                                ok0 = (v0 & kValid) != 0;
-                            }
-                            if (!ok1) {
-                                v1 = ld_granule(slot + G + lane);
-                                ok1 = (unsigned)(v1 >> 32) == tag;
-                            }
-                            if (!ok2) {
-                                v2 = ld_granule(slot + 2 * G + lane);
-                                ok2 = (unsigned)(v2 >> 32) == tag;
-                            }
-                            if (!ok3) {
-                                v3 = ld_granule(slot + 3 * G + lane);
-                                ok3 = (unsigned)(v3 >> 32) == tag;
-                            }
-                            if (ok0 && ok1 && ok2 && ok3) break;
+                            // four independent loads in flight per poll (a branch per load serialises them)
+                            v0 = ld_granule(slot + lane);
+                            v1 = ld_granule(slot + G + lane);
+                            v2 = ld_granule(slot + 2 * G + lane);
+                            v3 = ld_granule(slot + 3 * G + lane);
+                            const bool ok = ((v0 & kValid) != 0) & ((unsigned)(v1 >> 32) == tag) &
+                                            ((unsigned)(v2 >> 32) == tag) & ((unsigned)(v3 >> 32) == tag);
+                            if (ok) break;
                             if (++spins > kSpinLimit) {  // a member never arrived: flag it and let the grid drain
                                 atomicOr(err, 1u);
                                 v0 = kValid;
@@ -230,6 +234,267 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// XCD-local variant for medium clouds (8192 < N <= 524288).
+//
+// A granule hand-off between workgroups costs ~1400 cycles per hop when it has to cross XCDs (write-through store,
+// memory-side load) but only ~500 cycles when both workgroups share an XCD's L2: a plain store lands in that L2
+// and an L1-bypassing (sc1) load of a same-XCD reader hits it (tools/ubench/handoff.hip).  Correctness of that
+// cheaper form requires every member of a group to run on the SAME XCD, which HIP does not let a kernel choose --
+// so membership is decided at run time from where the workgroups actually landed: each workgroup reads its
+// HW_REG_XCC_ID, takes a rank on that XCD with a device-scope atomic, and after one grid-wide arrival count the
+// launch knows how many workgroups every XCD holds.  Groups of G consecutive ranks of one XCD own one cloud each
+// (plain-store granules); if no XCD holds G workgroups (busy GPU, odd placement) the launch falls back, as a
+// whole, to groups of consecutive block ids with the placement-independent write-through granules.  Either way
+// results are identical; only the speed depends on placement.
+constexpr int kXT = 1024, kXPPT = 8, kXGrid = 256;
+struct XcdHeader {
+    unsigned err, arrived, cnt[8], pad[6];
+};
+
+__device__ __forceinline__ unsigned xcc_id() {
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return v & 7u;
+}
+
+__global__ __launch_bounds__(kXT) void fps_xcd_kernel(const float* __restrict__ xyz, int64_t sb, int64_t sn, int64_t sc,
+                                                      int B, int N, int npoint, const int64_t* __restrict__ start,
+                                                      int32_t* __restrict__ out_idx, float* __restrict__ out_xyz,
+                                                      u64* gran, XcdHeader* hdr, int G) {
+    constexpr int T = kXT, NW = T / 64;
+    __shared__ u64 s_key[2][NW];
+    __shared__ float s_xyz[2][NW][3];
+    __shared__ u64 s_win[2];
+    __shared__ float s_wxyz[2][3];
+    __shared__ int s_role[4];  // {group id or -1, rank in group, number of groups, local?}
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // ---- phase 0: where did this workgroup land?  (one lane; everything below is wave-uniform)
+    if (tid == 0) {
+        const unsigned x = xcc_id();
+        const unsigned rank = atomicAdd(&hdr->cnt[x], 1u);
+        __threadfence();
+        atomicAdd(&hdr->arrived, 1u);
+        unsigned spins = 0;
+        bool ok = true;
+        while (__hip_atomic_load(&hdr->arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+            if (++spins > kSpinLimit) {
+                atomicOr(&hdr->err, 2u);
+                ok = false;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        int total = 0, before = 0, mine = 0;
+        for (unsigned k = 0; k < 8; ++k) {
+            const int c = (int)__hip_atomic_load(&hdr->cnt[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / G;
+            if (k < x) before += c;
+            if (k == x) mine = c;
+            total += c;
+        }
+        int group = -1, grank = 0, ngroups = 0, local = 0;
+        if (ok && total > 0) {  // XCD-local groups
+            local = 1;
+            ngroups = total;
+            if ((int)rank < mine * G) {
+                group = before + (int)rank / G;
+                grank = (int)rank % G;
+            }
+        } else if (ok) {        // placement-independent fallback: consecutive block ids
+            ngroups = (int)gridDim.x / G;
+            if ((int)blockIdx.x < ngroups * G) {
+                group = (int)blockIdx.x / G;
+                grank = (int)blockIdx.x % G;
+            }
+        }
+        s_role[0] = group;
+        s_role[1] = grank;
+        s_role[2] = ngroups;
+        s_role[3] = local;
+    }
+    __syncthreads();
+    const int group = s_role[0], g = s_role[1], ngroups = s_role[2];
+    const bool local = s_role[3] != 0;
+    if (group < 0 || ngroups <= 0) return;
+
+    const int ppt = (N + G * T - 1) / (G * T);  // <= kXPPT by the host's choice of G
+    const int base = g * (T * ppt) + tid;
+
+    for (int b = group; b < B; b += ngroups) {
+        const float* p = xyz + (int64_t)b * sb;
+        float x[kXPPT], y[kXPPT], z[kXPPT], d[kXPPT];
+#pragma unroll
+        for (int j = 0; j < kXPPT; ++j) {
+            const int n = base + j * T;
+            const bool ok = j < ppt && n < N;
+            const float* q = p + (int64_t)(ok ? n : 0) * sn;
+            x[j] = q[0];
+            y[j] = q[sc];
+            z[j] = q[2 * sc];
+            d[j] = ok ? 1e10f : -1.0f;
+        }
+        int far = (int)start[b];
+        float cx, cy, cz;
+        {
+            const float* c = p + (int64_t)far * sn;
+            cx = c[0];
+            cy = c[sc];
+            cz = c[2 * sc];
+        }
+        u64* gb = gran + (size_t)b * npoint * 4 * G;
+
+#ifdef PN2_FPS_DIAG
+        unsigned long long st[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
+        const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime(), ct0 = __builtin_amdgcn_s_memtime();
+#endif
+        for (int i = 0; i < npoint; ++i) {
+#ifdef PN2_FPS_DIAG
+            tprev = __builtin_amdgcn_s_memtime();
+#endif
+            if (g == 0 && tid == 0) {
+                out_idx[(size_t)b * npoint + i] = far;
+                if (out_xyz) {
+                    float* o = out_xyz + ((size_t)b * npoint + i) * 3;
+                    o[0] = cx;
+                    o[1] = cy;
+                    o[2] = cz;
+                }
+            }
+            if (i == npoint - 1) break;
+
+            float bestd = -1.0f, bx = 0.f, by = 0.f, bz = 0.f;
+            int bestj = 0;
+#pragma unroll
+            for (int j = 0; j < kXPPT; ++j) {
+                const float dx = __fsub_rn(x[j], cx), dy = __fsub_rn(y[j], cy), dz = __fsub_rn(z[j], cz);
+                const float dist = pn2::norm2(dx, dy, dz);
+                d[j] = dist < d[j] ? dist : d[j];
+                if (d[j] > bestd) {
+                    bestd = d[j];
+                    bestj = j;
+                    bx = x[j];
+                    by = y[j];
+                    bz = z[j];
+                }
+            }
+            const int bestn = base + bestj * T;
+            const u64 mykey =
+                bestd < 0.0f ? 0ull : (((u64)__float_as_uint(bestd)) << 32) | (u64)(0xFFFFFFFFu - (unsigned)bestn);
+            const u64 wkey = pn2::wave_max_u64(mykey);
+            const int buf = i & 1;
+            const u64 owners = __ballot(mykey == wkey);
+            if (lane == (int)__builtin_ctzll(owners)) {
+                s_key[buf][wave] = wkey;
+                s_xyz[buf][wave][0] = bx;
+                s_xyz[buf][wave][1] = by;
+                s_xyz[buf][wave][2] = bz;
+            }
+            STAMP(0);
+            lds_barrier();
+            STAMP(1);
+            // workgroup winner: lane w reads wave w's candidate, one DPP reduction (instead of a 16-deep compare
+            // chain in every thread).  With G > 1 only the publishing wave needs it.
+            u64 k = 0;
+            float nx = 0.f, ny = 0.f, nz = 0.f;
+            if (G == 1 || wave == 0) {
+                int kw = 0;
+                if (NW <= 4) {
+                    k = s_key[buf][0];
+#pragma unroll
+                    for (int w = 1; w < NW; ++w) {
+                        const u64 o = s_key[buf][w];
+                        if (o > k) {
+                            k = o;
+                            kw = w;
+                        }
+                    }
+                } else {
+                    const u64 cand = lane < NW ? s_key[buf][lane] : 0ull;
+                    k = pn2::wave_max_u64(cand);
+                    kw = (int)__builtin_ctzll(__ballot(lane < NW && cand == k));
+                }
+                nx = s_xyz[buf][kw][0];
+                ny = s_xyz[buf][kw][1];
+                nz = s_xyz[buf][kw][2];
+            }
+            if (G > 1) {
+                if (wave == 0) {
+                    u64* slot = gb + (size_t)i * 4 * G;
+                    const unsigned tag = (unsigned)(i + 1);
+                    if (lane < 4) {
+                        const float cxyz = lane == 1 ? nx : lane == 2 ? ny : nz;
+                        const u64 v = lane == 0 ? (k | kValid) : (((u64)tag) << 32) | (u64)__float_as_uint(cxyz);
+                        u64* dst = slot + (size_t)lane * G + g;
+                        if (local)  // plain store: stays in this XCD's L2, where the group's sc1 loads find it
+                            __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        else
+                            st_granule(dst, v);
+                    }
+                    STAMP(2);
+                    u64 v0 = kValid, v1 = 0, v2 = 0, v3 = 0;
+                    if (lane < G) {
+                        unsigned spins = 0;
+                        for (;;) {
+                            // four independent loads in flight per poll (a branch per load serialises them)
+                            v0 = ld_granule(slot + lane);
+                            v1 = ld_granule(slot + G + lane);
+                            v2 = ld_granule(slot + 2 * G + lane);
+                            v3 = ld_granule(slot + 3 * G + lane);
+                            const bool ok = ((v0 & kValid) != 0) & ((unsigned)(v1 >> 32) == tag) &
+                                            ((unsigned)(v2 >> 32) == tag) & ((unsigned)(v3 >> 32) == tag);
+                            if (ok) break;
+                            if (++spins > kSpinLimit) {
+                                atomicOr(&hdr->err, 1u);
+                                v0 = kValid;
+                                break;
+                            }
+                        }
+                    }
+                    STAMP(3);
+                    const u64 mine = v0 & ~kValid;
+                    const u64 best = pn2::wave_max_u64(mine);
+                    const u64 own = __ballot(lane < G && mine == best);
+                    if (lane == (int)__builtin_ctzll(own)) {
+                        s_win[buf] = best;
+                        s_wxyz[buf][0] = __uint_as_float((unsigned)v1);
+                        s_wxyz[buf][1] = __uint_as_float((unsigned)v2);
+                        s_wxyz[buf][2] = __uint_as_float((unsigned)v3);
+                    }
+                }
+                STAMP(4);
+                lds_barrier();
+                STAMP(5);
+                k = s_win[buf];
+                nx = s_wxyz[buf][0];
+                ny = s_wxyz[buf][1];
+                nz = s_wxyz[buf][2];
+            }
+            far = (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull));
+            cx = nx;
+            cy = ny;
+            cz = nz;
+        }
+#ifdef PN2_FPS_DIAG
+        if (tid == 0 && g == 0 && b == 0) {
+            unsigned long long* dbg = (unsigned long long*)((char*)hdr + 64);   // first granule bytes (diag only)
+            for (int k = 0; k < 6; ++k) dbg[k] = st[k];
+            dbg[6] = __builtin_amdgcn_s_memtime() - ct0;
+            dbg[7] = __builtin_amdgcn_s_memrealtime() - rt0;
+            dbg[8] = (unsigned long long)local;
+        }
+#endif
+        __syncthreads();
+    }
+}
+
+inline bool use_xcd_kernel(int N) {
+    if (getenv("PN2_FPS_NO_XCD")) return false;
+    return N > kXT * kXPPT && N <= 64 * kXT * kXPPT;
+}
+inline int xcd_group_size(int N) { return pn2::ceil_div(N, kXT * kXPPT); }
+
 struct Config {
     int ppt, t, G, groups;
     double cost;
@@ -267,6 +532,7 @@ void launch(const Config& c, const float* xyz, int64_t sb, int64_t sn, int64_t s
 
 extern "C" size_t pn2_fps_workspace_bytes(int B, int N, int npoint) {
     if (B <= 0 || N <= 0 || npoint <= 0) return 0;
+    if (use_xcd_kernel(N)) return sizeof(XcdHeader) + (size_t)B * npoint * 4 * xcd_group_size(N) * sizeof(u64);
     const Config c = pick(B, N);
     if (c.G == 0) return 0;
     // [err word padded to kHdr bytes][granules: 4 per (cloud, step, member)]
@@ -277,6 +543,18 @@ extern "C" int pn2_fps_f32(const float* xyz, int64_t sb, int64_t sn, int64_t sc,
                            const int64_t* start, int32_t* out_idx, float* out_xyz, void* workspace,
                            size_t workspace_bytes, void* stream) {
     if (!xyz || !start || !out_idx || !workspace || B <= 0 || N <= 0 || npoint <= 0) return PN2_E_BADARG;
+    if (use_xcd_kernel(N)) {
+        const size_t need = pn2_fps_workspace_bytes(B, N, npoint);
+        if (workspace_bytes < need) return PN2_E_WORKSPACE;
+        hipStream_t s = (hipStream_t)stream;
+        PN2_HIP_CHECK(hipMemsetAsync(workspace, 0, need, s));
+        XcdHeader* hdr = (XcdHeader*)workspace;
+        u64* gran = (u64*)((char*)workspace + sizeof(XcdHeader));
+        PN2_LAUNCH("fps", (double)B * (12.0 * N + 8.0 * npoint), 0, fps_xcd_kernel, dim3(kXGrid), dim3(kXT), s, xyz, sb, sn, sc, B, N,
+                   npoint, start, out_idx, out_xyz, gran, hdr, xcd_group_size(N));
+        PN2_LAUNCH_CHECK();
+        return 0;
+    }
     const Config c = pick(B, N);
     if (c.G == 0) return PN2_E_BADARG;  // N beyond 64 members x 16384 points (1,048,576)
     const size_t need = pn2_fps_workspace_bytes(B, N, npoint);

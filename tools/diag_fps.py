@@ -21,7 +21,10 @@ for (N, npoint, B) in [(262144, 1024, 1), (2500, 100, 10), (1024, 256, 1)]:
                              ws.data_ptr(), nb, torch.cuda.current_stream().cuda_stream)
         assert st == 0
         torch.cuda.synchronize()
-    d = ws[16:16 + 64].view(torch.int64).cpu().numpy()
+    xcd = 8192 < N <= 524288
+    d = (ws[64:64 + 72] if xcd else ws[16:16 + 64]).view(torch.int64).cpu().numpy()
+    if xcd:
+        print("  (xcd kernel, local =", int(d[8]), ")")
     tot, rt = d[6], d[7]
     print(f"N={N} npoint={npoint} B={B}: {tot / npoint:.0f} cycles/step, clock {tot / (rt / 100.0):.0f} MHz, "
           + " ".join(f"{n}={v / npoint:.0f}" for n, v in zip(["compute", "bar1", "scan+pub", "poll", "reduce", "bar2"], d[:6])))
