@@ -371,7 +371,98 @@ def _make_model(depth, n_real, n_pad, seed_t, centre):
     return True
 
 
+# --------------------------------------------------------------------------------------- streaming mode (a11)
+class _FakeScaler:
+    """GradScaler stand-in: scale(x) = x (the reference only calls scaler.scale(loss).backward() inside the model)."""
+
+    def scale(self, x):
+        return x
+
+
+def make_streaming():
+    """forward_hierarchical_streaming (PointNet2.py:210-327) hard-codes device="cuda"; to run the REFERENCE's own
+    loop on this CPU-only host, "cuda" is mapped to "cpu" in torch.zeros / Tensor.to for the duration of the call."""
+    helpers.load_pkg()
+    from pn2_amd.synthetic import gaussian_branch_tree, rasterize
+    xyz, off, _ = gaussian_branch_tree(20000, seed=5)
+    rasters = [r for r in rasterize(xyz, 2.0, 2.0) if len(r) >= 40][:6]
+    feats_all = sinpat((len(xyz), 4), 7)
+    ids_all = np.concatenate(rasters)
+    cloud_length = int(len(xyz))
+    sem_lab = (np.arange(cloud_length) % 3 == 0).astype(np.int64)
+
+    def mini_batches(to_t):
+        for k in range(0, len(rasters), 2):
+            group = rasters[k:k + 2]
+            nmax = max(len(r) for r in group)
+            coords = np.zeros((len(group), 3, nmax), np.float32)
+            fts = np.zeros((len(group), 4, nmax), np.float32)
+            mpad = np.zeros((len(group), nmax), bool)
+            for i, r in enumerate(group):
+                # raster-relative coordinates: keeps the fixture free of exact 3rd/4th-neighbour ties (see make_model)
+                coords[i, :, :len(r)] = (xyz[r] - np.floor(xyz[r].min(axis=0))).T
+                fts[i, :, :len(r)] = feats_all[r].T
+                mpad[i, :len(r)] = True
+            ids = np.concatenate(group)
+            moff = (np.arange(len(ids)) % 5) != 2
+            yield {"coords": to_t(coords), "feats": to_t(fts), "masks_pad": to_t(mpad), "masks_off": to_t(moff),
+                   "point_ids": to_t(ids)}
+
+    zeros, to = torch.zeros, torch.Tensor.to
+
+    def zeros_cpu(*a, **k):
+        if k.get("device") == "cuda":
+            k["device"] = "cpu"
+        return zeros(*a, **k)
+
+    def to_cpu(self, *a, **k):
+        a = tuple("cpu" if (isinstance(x, str) and x == "cuda") else x for x in a)
+        return to(self, *a, **k)
+
+    # inputs are regenerated in the test from the same seeded recipe (gaussian_branch_tree(20000, seed=5),
+    # rasterize(2.0), sinpat features); only the raster index lists and the reference's outputs are stored
+    out = {"n_rasters": np.int64(len(rasters))}
+    for i, r in enumerate(rasters):
+        out[f"raster{i}"] = r.astype(np.int32)
+    torch.zeros, torch.Tensor.to = zeros_cpu, to_cpu
+    import contextlib
+    try:
+        for f64 in (False, True):
+            tag = "_f64" if f64 else ""
+            with (_f64_layers() if f64 else contextlib.nullcontext()):
+                torch.manual_seed(WEIGHT_SEED)
+                model = RP.PointNet2(depth=5)
+                model.train()
+                batch = {"cloud_length": cloud_length, "mini_batches": mini_batches(torch.from_numpy),
+                         "semantic_labels": torch.from_numpy(sem_lab)[:, None], "offset_labels": torch.from_numpy(off)}
+                torch.manual_seed(31)
+                avg_loss, ld = model.forward_hierarchical_streaming(batch, return_loss=True, scaler=_FakeScaler())
+                names, l2, s1 = grad_summary(model)
+                out.update({"avg_loss" + tag: np.float64(avg_loss), "offset_loss" + tag: np.float32(ld["offset_loss"].item()),
+                            "semantic_loss" + tag: np.float32(ld["semantic_loss"].item()), "grad_names": names,
+                            "grad_l2" + tag: l2})
+                # inference pass on the same (now updated running stats, still train-mode) model
+                batch["mini_batches"] = mini_batches(torch.from_numpy)
+                torch.manual_seed(32)
+                with torch.no_grad():
+                    pred = model.forward_hierarchical_streaming(batch, return_loss=False)
+                out["pred_offsets" + tag] = t2n(pred["offset_predictions"])
+                out["pred_logits" + tag] = t2n(pred["semantic_prediction_logits"])
+    finally:
+        torch.zeros, torch.Tensor.to = zeros, to
+    rel = float(np.abs(out["pred_offsets"] - out["pred_offsets_f64"]).max() / np.abs(out["pred_offsets_f64"]).max())
+    gn = float(np.max(np.abs(out["grad_l2"] - out["grad_l2_f64"]) / np.maximum(out["grad_l2_f64"], 1e-3 * out["grad_l2_f64"].max())))
+    print(f"  streaming: reference fp32 vs float64 arithmetic: offsets {rel:.2e}, gradient norms {gn:.2e}")
+    print("  streaming: FP boundary ties:", _fp_ties[0])
+    assert _fp_ties[0] == 0
+    save("streaming_d5.npz", **out)
+
+
 if __name__ == "__main__":
+    if "--only-streaming" in sys.argv:
+        make_streaming()
+        raise SystemExit(0)
+    make_streaming()
     make_ops()
     make_blocks()
     make_model(5, [1024, 640], 1024, 11)
