@@ -24,7 +24,7 @@
 
 namespace {
 
-constexpr int BK = 32, NT = 256;
+constexpr int BK = 16, NT = 256;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 enum { TR_PLAIN = 0, TR_BNRELU = 1, TR_DY = 2 };
@@ -68,7 +68,9 @@ __device__ __forceinline__ float4 ld4(const float* base, long long ld, int r, in
 // layout (reloaded per K-tile), the outer index for the D layout (loaded once).
 template <bool T_LAYOUT, int KIND, int TILE, bool VEC>
 struct Stager {
-    static constexpr int NP = TILE / 32;
+    static constexpr int NP = TILE * BK / (4 * NT);   // 16-byte loads per thread per K-tile
+    static constexpr int KT = BK / 4;        // T layout: threads along k per row
+    static constexpr int RPP = NT / KT;      // T layout: rows per pass
     static constexpr int OQ = TILE / 4;      // D layout: threads per k-row
     static constexpr int KPP = NT / OQ;      // D layout: k-rows per pass
     static constexpr int LD = TILE + 4;
@@ -76,13 +78,29 @@ struct Stager {
     float cm[4], cs[4], cb[4], ca[4], cq[4];
 
     __device__ __forceinline__ int chan0(int o0, int k0) const {
-        return T_LAYOUT ? k0 + 4 * ((int)threadIdx.x & 7) : o0 + 4 * ((int)threadIdx.x % OQ);
+        return T_LAYOUT ? k0 + 4 * ((int)threadIdx.x % KT) : o0 + 4 * ((int)threadIdx.x % OQ);
     }
     __device__ __forceinline__ int row_of(int p, int o0, int k0) const {
-        return T_LAYOUT ? o0 + 32 * p + ((int)threadIdx.x >> 3) : k0 + KPP * p + ((int)threadIdx.x / OQ);
+        return T_LAYOUT ? o0 + RPP * p + ((int)threadIdx.x / KT) : k0 + KPP * p + ((int)threadIdx.x / OQ);
     }
     __device__ __forceinline__ void load_coefs(const Operand& o, int c0) {
         if (KIND == TR_PLAIN) return;
+        if (VEC) {  // cols % 4 == 0: one 16-byte load per coefficient row (the block is [8][cols], 16-byte aligned)
+            const int cc = c0 < o.cols ? c0 : o.cols - 4;
+            const float4 m4 = *(const float4*)(o.coef + ST_MEAN * o.cstride + cc);
+            const float4 s4 = *(const float4*)(o.coef + ST_SCALE * o.cstride + cc);
+            const float4 b4 = *(const float4*)(o.coef + ST_BETA * o.cstride + cc);
+            cm[0] = m4.x; cm[1] = m4.y; cm[2] = m4.z; cm[3] = m4.w;
+            cs[0] = s4.x; cs[1] = s4.y; cs[2] = s4.z; cs[3] = s4.w;
+            cb[0] = b4.x; cb[1] = b4.y; cb[2] = b4.z; cb[3] = b4.w;
+            if (KIND == TR_DY) {
+                const float4 a4 = *(const float4*)(o.coef + ST_A * o.cstride + cc);
+                const float4 q4 = *(const float4*)(o.coef + ST_B * o.cstride + cc);
+                ca[0] = a4.x; ca[1] = a4.y; ca[2] = a4.z; ca[3] = a4.w;
+                cq[0] = q4.x; cq[1] = q4.y; cq[2] = q4.z; cq[3] = q4.w;
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int ch = c0 + j < o.cols ? c0 + j : o.cols - 1;
@@ -118,29 +136,31 @@ struct Stager {
         const float dz = (!relu || t > 0.0f) ? val : 0.0f;
         return cs[j] * (dz - ca[j] - (yy - cm[j]) * cq[j]);
     }
-    __device__ __forceinline__ void commit(const Operand& o, float* S, int o0, int k0) {
+    // stage pass p of the fetched tile into the LDS image (transform applied here, once per element)
+    __device__ __forceinline__ void commit_pass(const Operand& o, float* S, int o0, int k0, int p) {
         const int c = chan0(o0, k0);
+        const int r = row_of(p, o0, k0);
+        const float e[4] = {v[p].x, v[p].y, v[p].z, v[p].w};
+        const float yy[4] = {y[p].x, y[p].y, y[p].z, y[p].w};
+        float w[4];
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            const int r = row_of(p, o0, k0);
-            const float e[4] = {v[p].x, v[p].y, v[p].z, v[p].w};
-            const float yy[4] = {y[p].x, y[p].y, y[p].z, y[p].w};
-            float w[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                // elements outside the matrix must be exactly zero: they pad the contraction
-                const bool in = r < o.rows && c + j < o.cols;
-                w[j] = in ? xf(e[j], KIND == TR_DY ? yy[j] : 0.0f, j, o.relu) : 0.0f;
-            }
-            if (T_LAYOUT) {
-                const int m = 32 * p + ((int)threadIdx.x >> 3), k = 4 * ((int)threadIdx.x & 7);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) S[(k + j) * LD + m] = w[j];
-            } else {
-                const int k = KPP * p + ((int)threadIdx.x / OQ), m = 4 * ((int)threadIdx.x % OQ);
-                *(float4*)(S + k * LD + m) = make_float4(w[0], w[1], w[2], w[3]);
-            }
+        for (int j = 0; j < 4; ++j) {
+            // elements outside the matrix must be exactly zero: they pad the contraction
+            const bool in = r < o.rows && c + j < o.cols;
+            w[j] = in ? xf(e[j], KIND == TR_DY ? yy[j] : 0.0f, j, o.relu) : 0.0f;
         }
+        if (T_LAYOUT) {
+            const int m = RPP * p + ((int)threadIdx.x / KT), k = 4 * ((int)threadIdx.x % KT);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) S[(k + j) * LD + m] = w[j];
+        } else {
+            const int k = KPP * p + ((int)threadIdx.x / OQ), m = 4 * ((int)threadIdx.x % OQ);
+            *(float4*)(S + k * LD + m) = make_float4(w[0], w[1], w[2], w[3]);
+        }
+    }
+    __device__ __forceinline__ void commit(const Operand& o, float* S, int o0, int k0) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) commit_pass(o, S, o0, k0, p);
     }
 };
 
@@ -163,7 +183,7 @@ struct GemmArgs {
 // TILE = 128: four waves own 64 x 64 each (2 x 2 MFMA accumulators); TILE = 64: 32 x 32 each (one accumulator),
 // for problems too small to fill the chip with 128-tiles.
 template <bool A_T, int A_KIND, bool B_T, int B_KIND, int EPI, int TILE, bool VEC>
-__global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(NT, (EPI == EPI_STORE ? 2 : 3)) void gemm_kernel(const GemmArgs g) {
     constexpr int LD = TILE + 4, WT = TILE / 2, NI = WT / 32;
     __shared__ __attribute__((aligned(16))) float As[2][BK * LD];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK * LD];
@@ -206,23 +226,31 @@ __global__ __launch_bounds__(NT) void gemm_kernel(const GemmArgs g) {
         }
         const float* a = As[cur] + wm * WT + l31;
         const float* b = Bs[cur] + wn * WT + l31;
+        // The K-tile's MFMAs are issued in NP groups; after each group one pass of the NEXT tile is staged into the
+        // other LDS buffer, so the staging VALU/LDS work sits in the shadow of the (asynchronous, 64-cycle) MFMAs
+        // instead of forming a separate phase during which this wave's matrix pipe idles.
+        constexpr int NP = TILE * BK / (4 * NT), KQ = BK / NP;
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            const int ko = (kk + half) * LD;
-            float av[NI], bv[NI];
+        for (int q = 0; q < NP; ++q) {
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                av[i] = a[ko + 32 * i];
-                bv[i] = b[ko + 32 * i];
+            for (int kk = q * KQ; kk < (q + 1) * KQ; kk += 2) {
+                const int ko = (kk + half) * LD;
+                float av[NI], bv[NI];
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    av[i] = a[ko + 32 * i];
+                    bv[i] = b[ko + 32 * i];
+                }
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
             }
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-#pragma unroll
-                for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-        }
-        if (kt + 1 < nk) {
-            sa.commit(g.A, As[cur ^ 1], m0, knext);
-            sb.commit(g.B, Bs[cur ^ 1], n0, knext);
+            if (kt + 1 < nk) {
+                sa.commit_pass(g.A, As[cur ^ 1], m0, knext, q);
+                sb.commit_pass(g.B, Bs[cur ^ 1], n0, knext, q);
+            }
         }
         __syncthreads();
     }
