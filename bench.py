@@ -80,7 +80,7 @@ def main():
     torch.manual_seed(0)                                  # identical random-init weights on every rank
     model = PointNet2(depth=args.depth, loss_multiplier_semantic=0).to(dev).train()
     grads = parallel.FlatGradAllReduce(model)
-    opt = torch.optim.AdamW(model.parameters(), lr=0.01, weight_decay=1e-3)   # train_PointNet2.py:250
+    opt = torch.optim.AdamW(model.parameters(), lr=0.01, weight_decay=1e-3, fused=True)   # train_PointNet2.py:250
     batch = make_batch(args.points, seed=rank, device=dev)
     torch.manual_seed(1000 + rank)                        # FPS start indices: per-rank stream
 

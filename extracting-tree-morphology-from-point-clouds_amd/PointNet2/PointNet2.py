@@ -9,6 +9,7 @@ import functools
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from ..Loss import point_wise_loss
 from ..Utils import cuda_cast
@@ -112,10 +113,38 @@ class PointNet2(nn.Module):
         return sem.index_select(0, keep), off.index_select(0, keep_off)
 
     def get_loss(self, model_output, semantic_labels, offset_labels, masks_off, masks_pad, **kwargs):
-        sem, off = self._valid_rows(model_output["semantic_prediction_logits"], model_output["offset_predictions"],
-                                    masks_pad, masks_off)
-        return self.get_loss_hierarchical({"semantic_prediction_logits": sem, "offset_predictions": off},
-                                          semantic_labels, offset_labels)
+        """Flattened-mode loss (reference lines 180-207): padding mask, then offset mask, then point_wise_loss.
+
+        The reference compacts the predictions with boolean indexing, which needs the number of selected rows on
+        the host (a device->host sync in the middle of every step) and an index_put_ in backward.  The same two
+        means are computed here WITHOUT compaction: the compacted label arrays are expanded to the padded rows with
+        a cumulative-sum rank, and the per-row losses are summed under the masks and divided by the mask counts
+        (all on the device, no sync).  Values agree with point_wise_loss on the compacted rows to fp32 rounding
+        (tests/test_hip_parity.py::test_get_loss_matches_compacted_form)."""
+        sem = model_output["semantic_prediction_logits"].permute(0, 2, 1).reshape(-1, 2).float()
+        off = model_output["offset_predictions"].permute(0, 2, 1).reshape(-1, 3).float()
+        if semantic_labels.numel() == 0 or offset_labels.numel() == 0 or masks_off.numel() == 0:
+            sem_v, off_v = self._valid_rows(model_output["semantic_prediction_logits"],
+                                            model_output["offset_predictions"], masks_pad, masks_off)
+            return self.get_loss_hierarchical({"semantic_prediction_logits": sem_v, "offset_predictions": off_v},
+                                              semantic_labels, offset_labels)
+        pad = masks_pad.reshape(-1)
+        rank = torch.cumsum(pad, 0) - 1                      # index of a real row among the real rows
+        n_valid = (rank[-1] + 1).clamp_min(1)
+        rank = rank.clamp(0, semantic_labels.numel() - 1)
+        sem_labels = semantic_labels.reshape(-1).index_select(0, rank)
+        off_mask = pad & masks_off.index_select(0, rank.clamp_max(masks_off.numel() - 1))
+        rank_off = torch.cumsum(off_mask, 0) - 1
+        n_off = (rank_off[-1] + 1).clamp_min(1)
+        off_labels = offset_labels.index_select(0, rank_off.clamp(0, offset_labels.shape[0] - 1))
+
+        ce = F.cross_entropy(sem, sem_labels, reduction="none")
+        semantic_loss = (ce * pad).sum() / n_valid
+        dist = torch.sqrt(torch.clamp((off - off_labels).pow(2).sum(1), min=1e-8))
+        offset_loss = (dist * off_mask).sum() / n_off
+        loss_dict = {"semantic_loss": semantic_loss * self.loss_multiplier_semantic,
+                     "offset_loss": offset_loss * self.loss_multiplier_offset}
+        return sum(loss_dict.values()), loss_dict
 
     def get_loss_hierarchical(self, model_output, semantic_labels, offset_labels, **kwargs):
         semantic_loss, offset_loss = point_wise_loss(model_output["semantic_prediction_logits"].float(),

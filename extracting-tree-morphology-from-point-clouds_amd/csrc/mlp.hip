@@ -592,12 +592,202 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ d
     }
 }
 
-__global__ void colsum_finalize_kernel(const float* __restrict__ partial, int nblk, int C, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// one 64-thread block per channel: lanes split the partial blocks, DPP-free shuffle tree, float64 accumulation
+__global__ __launch_bounds__(64) void colsum_finalize_kernel(const float* __restrict__ partial, int nblk, int C,
+                                                             float* __restrict__ out) {
+    const int c = blockIdx.x;
     double a = 0.0;
-    for (int k = 0; k < nblk; ++k) a += (double)partial[(long long)k * C + c];
-    out[c] += (float)a;
+    for (int k = threadIdx.x; k < nblk; k += 64) a += (double)partial[(long long)k * C + c];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+    if (threadIdx.x == 0) out[c] += (float)a;
+}
+
+// ------------------------------------------------------------------------------------- narrow last layer (heads)
+// The 128 -> 2 / 128 -> 3 convs that end the two heads are matrix-vector shaped: on the 128-wide MFMA tile they cost
+// as much matrix-pipe time as a full layer for 2 % of its useful work.  They run on the vector ALU instead, one
+// pass over the rows each way: a row's K channels are spread over KL = K/4 lanes (16-byte loads), the N <= 4
+// outputs are reduced across those lanes with DPP row operations.
+//   forward : out[r][n] = b[n] + sum_k act(Y[r][k]) W[n][k]
+//   backward: dX[r][k] = sum_n dO[r][n] W[n][k]  (written);  per-block partials of dW[n][k] = sum_r dO[r][n] act(Y[r][k]),
+//             db[n] = sum_r dO[r][n] and, when the input comes through a BatchNorm, that layer's backward sums
+//             s1[k] = sum_r mask*dX, s2[k] = sum_r mask*dX*xhat -- everything the generic path needs three GEMM
+//             launches and a reduction pass for.
+constexpr int NR_ROWS = 1024;  // rows per block
+constexpr int NR_T = 1024;     // threads per block: 16 waves per CU hide the load latency, 256 blocks keep the partials few
+constexpr int NMAX = 4;
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+// sum over each aligned group of KL lanes (KL = 16, 32 or 64); valid in the LAST lane of the group
+template <int KL>
+__device__ __forceinline__ float group_sum(float v) {
+    v = dpp_add<0x111, 0xF>(v);
+    v = dpp_add<0x112, 0xF>(v);
+    v = dpp_add<0x114, 0xF>(v);
+    v = dpp_add<0x118, 0xF>(v);                      // lane 15 of every 16-lane row
+    if (KL >= 32) v = dpp_add<0x142, 0xA>(v);        // row_bcast:15 -> lanes 31 and 63
+    if (KL >= 64) v = dpp_add<0x143, 0xC>(v);        // row_bcast:31 -> lane 63
+    return v;
+}
+
+template <int KL, bool HAS_BN>
+__global__ __launch_bounds__(NR_T) void narrow_fwd_kernel(const float* __restrict__ y, long long ldy, int rows, int K,
+                                                         const float* __restrict__ coef, int relu,
+                                                         const float* __restrict__ W, const float* __restrict__ bias, int N,
+                                                         float* __restrict__ out) {
+    constexpr int RPW = 64 / KL;                      // rows per wave per step
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kq = lane % KL, rsub = lane / KL, k = 4 * kq;
+    float w[NMAX][4], cm[4], cs[4], cb[4];
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[n][j] = n < N ? W[(long long)n * K + k + j] : 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        cm[j] = HAS_BN ? coef[ST_MEAN * K + k + j] : 0.0f;
+        cs[j] = HAS_BN ? coef[ST_SCALE * K + k + j] : 1.0f;
+        cb[j] = HAS_BN ? coef[ST_BETA * K + k + j] : 0.0f;
+    }
+    const int r0 = blockIdx.x * NR_ROWS;
+    const int r1 = r0 + NR_ROWS < rows ? r0 + NR_ROWS : rows;
+    constexpr int RGF = (NR_T / 64) * RPW;
+    const int iters = (r1 - r0 + RGF - 1) / RGF;   // uniform trip count: the DPP sums need every lane
+    for (int it = 0; it < iters; ++it) {
+        const int rb = r0 + it * RGF + wave * RPW + rsub;
+        const int r = rb < r1 ? rb : r1 - 1;
+        const float4 v = *(const float4*)(y + (long long)r * ldy + k);
+        const float e[4] = {v.x, v.y, v.z, v.w};
+        float p[NMAX] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float x = e[j];
+            if (HAS_BN) {
+                x = __builtin_fmaf(x - cm[j], cs[j], cb[j]);
+                if (relu) x = fmaxf(x, 0.0f);
+            }
+#pragma unroll
+            for (int n = 0; n < NMAX; ++n) p[n] = __builtin_fmaf(x, w[n][j], p[n]);
+        }
+#pragma unroll
+        for (int n = 0; n < NMAX; ++n) p[n] = group_sum<KL>(p[n]);
+        if (kq == KL - 1 && rb < r1) {
+            for (int n = 0; n < N; ++n) out[(long long)r * N + n] = p[n] + (bias ? bias[n] : 0.0f);
+        }
+    }
+}
+
+template <int KL, bool HAS_BN>
+__global__ __launch_bounds__(NR_T) void narrow_bwd_kernel(const float* __restrict__ dout, int rows, int K, int N,
+                                                         const float* __restrict__ y, long long ldy,
+                                                         const float* __restrict__ coef, int relu,
+                                                         const float* __restrict__ W, float* __restrict__ dx,
+                                                         float* __restrict__ part_s, float* __restrict__ part_w,
+                                                         float* __restrict__ part_b) {
+    constexpr int RPW = 64 / KL, RG = (NR_T / 64) * RPW;       // row groups per block
+    __shared__ float red[RG][KL][4 * NMAX + 8];
+    __shared__ float redb[4][NMAX];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kq = lane % KL, rsub = lane / KL, k = 4 * kq, rgp = wave * RPW + rsub;
+    float w[NMAX][4], cm[4], cs[4], cb[4], ci[4];
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[n][j] = n < N ? W[(long long)n * K + k + j] : 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        cm[j] = HAS_BN ? coef[ST_MEAN * K + k + j] : 0.0f;
+        cs[j] = HAS_BN ? coef[ST_SCALE * K + k + j] : 1.0f;
+        cb[j] = HAS_BN ? coef[ST_BETA * K + k + j] : 0.0f;
+        ci[j] = HAS_BN ? coef[ST_INVSTD * K + k + j] : 0.0f;
+    }
+    float dw[NMAX][4], s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f}, db[NMAX] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dw[n][j] = 0.0f;
+    const int r0 = blockIdx.x * NR_ROWS;
+    const int r1 = r0 + NR_ROWS < rows ? r0 + NR_ROWS : rows;
+    for (int r = r0 + rgp; r < r1; r += RG) {
+        const float4 v = *(const float4*)(y + (long long)r * ldy + k);
+        const float e[4] = {v.x, v.y, v.z, v.w};
+        float g[NMAX];
+#pragma unroll
+        for (int n = 0; n < NMAX; ++n) g[n] = n < N ? dout[(long long)r * N + n] : 0.0f;
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float x = e[j], t = 1.0f;
+            if (HAS_BN) {
+                t = __builtin_fmaf(x - cm[j], cs[j], cb[j]);
+                x = relu ? fmaxf(t, 0.0f) : t;
+            }
+            float d = 0.0f;
+#pragma unroll
+            for (int n = 0; n < NMAX; ++n) {
+                d = __builtin_fmaf(g[n], w[n][j], d);
+                dw[n][j] = __builtin_fmaf(g[n], x, dw[n][j]);
+            }
+            o[j] = d;
+            if (HAS_BN) {
+                const float dzh = (!relu || t > 0.0f) ? d : 0.0f;
+                s1[j] += dzh;
+                s2[j] += dzh * ((e[j] - cm[j]) * ci[j]);
+            }
+        }
+        *(float4*)(dx + (long long)r * K + k) = make_float4(o[0], o[1], o[2], o[3]);
+        if (kq == 0)
+#pragma unroll
+            for (int n = 0; n < NMAX; ++n) db[n] += g[n];
+    }
+    // block reduction over the RG row groups, fixed order
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[rgp][kq][4 * n + j] = dw[n][j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        red[rgp][kq][4 * NMAX + j] = s1[j];
+        red[rgp][kq][4 * NMAX + 4 + j] = s2[j];
+    }
+    __syncthreads();
+    if (rgp == 0) {
+        float acc[4 * NMAX + 8];
+#pragma unroll
+        for (int q = 0; q < 4 * NMAX + 8; ++q) acc[q] = red[0][kq][q];
+        for (int gI = 1; gI < RG; ++gI)
+#pragma unroll
+            for (int q = 0; q < 4 * NMAX + 8; ++q) acc[q] += red[gI][kq][q];
+        for (int n = 0; n < N; ++n)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) part_w[((long long)blockIdx.x * N + n) * K + k + j] = acc[4 * n + j];
+        if (HAS_BN)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                part_s[((long long)blockIdx.x * 2 + 0) * K + k + j] = acc[4 * NMAX + j];
+                part_s[((long long)blockIdx.x * 2 + 1) * K + k + j] = acc[4 * NMAX + 4 + j];
+            }
+    }
+    // bias column sums: lanes with kq == 0 hold them, one per row group
+    __syncthreads();
+    float* rb = &red[0][0][0];
+    if (kq == 0)
+#pragma unroll
+        for (int n = 0; n < NMAX; ++n) rb[rgp * NMAX + n] = db[n];
+    __syncthreads();
+    if (threadIdx.x < (unsigned)N) {
+        float a = 0.0f;
+        for (int gI = 0; gI < RG; ++gI) a += rb[gI * NMAX + threadIdx.x];
+        part_b[(long long)blockIdx.x * N + threadIdx.x] = a;
+    }
+    (void)redb;
+}
+
+inline bool narrow_ok(const pn2_mlp_layer& L, bool last, int pool_k) {
+    return last && !L.has_bn && pool_k <= 1 && L.cout <= NMAX && (L.cin == 64 || L.cin == 128 || L.cin == 256);
 }
 
 inline unsigned grid1d(long long total, int per_block = 256) {
@@ -667,6 +857,45 @@ int launch_gemm(GemmArgs& g, int nsplit, int tile, hipStream_t s) {
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+template <int KL>
+int launch_narrow_fwd_kl(const Act& in, int rows, const pn2_mlp_layer& L, float* out, hipStream_t s) {
+    const dim3 grid(pn2::ceil_div(rows, NR_ROWS)), block(NR_T);
+    const double bytes = 4.0 * rows * (L.cin + L.cout), flops = 2.0 * rows * L.cin * L.cout;
+    if (in.coef)
+        PN2_LAUNCH("narrow_fwd", bytes, flops, (narrow_fwd_kernel<KL, true>), grid, block, s, in.p, in.ld, rows, L.cin, in.coef,
+                   in.relu, L.weight, L.bias, L.cout, out);
+    else
+        PN2_LAUNCH("narrow_fwd", bytes, flops, (narrow_fwd_kernel<KL, false>), grid, block, s, in.p, in.ld, rows, L.cin, in.coef,
+                   in.relu, L.weight, L.bias, L.cout, out);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+int launch_narrow_fwd(const Act& in, int rows, const pn2_mlp_layer& L, float* out, hipStream_t s) {
+    return L.cin == 64 ? launch_narrow_fwd_kl<16>(in, rows, L, out, s)
+                       : L.cin == 128 ? launch_narrow_fwd_kl<32>(in, rows, L, out, s) : launch_narrow_fwd_kl<64>(in, rows, L, out, s);
+}
+
+template <int KL>
+int launch_narrow_bwd_kl(const Act& in, int rows, const pn2_mlp_layer& L, const float* dout, float* dx, float* part_s,
+                         float* part_w, float* part_b, hipStream_t s) {
+    const dim3 grid(pn2::ceil_div(rows, NR_ROWS)), block(NR_T);
+    const double bytes = 4.0 * rows * (2.0 * L.cin + L.cout), flops = 4.0 * rows * L.cin * L.cout;
+    if (in.coef)
+        PN2_LAUNCH("narrow_bwd", bytes, flops, (narrow_bwd_kernel<KL, true>), grid, block, s, dout, rows, L.cin, L.cout, in.p, in.ld,
+                   in.coef, in.relu, L.weight, dx, part_s, part_w, part_b);
+    else
+        PN2_LAUNCH("narrow_bwd", bytes, flops, (narrow_bwd_kernel<KL, false>), grid, block, s, dout, rows, L.cin, L.cout, in.p, in.ld,
+                   in.coef, in.relu, L.weight, dx, part_s, part_w, part_b);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+int launch_narrow_bwd(const Act& in, int rows, const pn2_mlp_layer& L, const float* dout, float* dx, float* part_s,
+                      float* part_w, float* part_b, hipStream_t s) {
+    return L.cin == 64 ? launch_narrow_bwd_kl<16>(in, rows, L, dout, dx, part_s, part_w, part_b, s)
+           : L.cin == 128 ? launch_narrow_bwd_kl<32>(in, rows, L, dout, dx, part_s, part_w, part_b, s)
+                          : launch_narrow_bwd_kl<64>(in, rows, L, dout, dx, part_s, part_w, part_b, s);
+}
+
 struct WgradPlan {
     int tile, nsplit, kps;
 };
@@ -695,8 +924,11 @@ extern "C" size_t pn2_mlp_workspace_bytes(int rows, const pn2_mlp_layer* layers,
         const size_t cs = (size_t)pn2::ceil_div(rows, CS_ROWS) * cout * sizeof(float);         // bias column sums
         const WgradPlan wp = plan_wgrad(rows, (int)cout, (int)cin);
         const size_t slab = (size_t)wp.nsplit * cout * cin * sizeof(float);
+        const size_t nblk = (size_t)pn2::ceil_div(rows, NR_ROWS);
+        const size_t narrow = nblk * (2 * cin + cout * cin + cout) * sizeof(float);           // narrow_bwd partials
         size_t m = part > cs ? part : cs;
         m = m > slab ? m : slab;
+        m = m > narrow ? m : narrow;
         need = need > m ? need : m;
     }
     return align256(need) + 256;
@@ -727,8 +959,13 @@ extern "C" int pn2_mlp_chain_fwd_f32(const float* x, int64_t ldx, int rows, cons
         g.bias = L.bias;
         g.partial = (L.has_bn && training) ? (float*)workspace : nullptr;
         const int tile = pick_tile(rows, L.cout, 1);
-        int st = in.coef ? launch_gemm<true, TR_BNRELU, true, TR_PLAIN, EPI_FWD>(g, 1, tile, s)
+        int st = 0;
+        if (narrow_ok(L, last, pool_k) && in.ld % 4 == 0 && aligned16(in.p)) {
+            st = launch_narrow_fwd(in, rows, L, y, s);
+        } else {
+            st = in.coef ? launch_gemm<true, TR_BNRELU, true, TR_PLAIN, EPI_FWD>(g, 1, tile, s)
                          : launch_gemm<true, TR_PLAIN, true, TR_PLAIN, EPI_FWD>(g, 1, tile, s);
+        }
         if (st) return st;
         if (L.has_bn) {
             if (training) {
@@ -788,7 +1025,7 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
         dz = bufs[which];
         which ^= 1;
     }
-    int fused_chunk = 0;  // > 0: the BatchNorm-backward partials of the current layer are already in ws (chunk rows)
+    int fused_nblk = 0;  // > 0: the BatchNorm-backward partials of the current layer are already in ws (that many blocks)
     for (int i = nlayers - 1; i >= 0; --i) {
         const pn2_mlp_layer& L = layers[i];
         const bool last = i == nlayers - 1;
@@ -796,8 +1033,8 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
         // ---- BatchNorm backward reductions -> coefficients a, b and dgamma, dbeta
         if (L.has_bn) {
             int nblk;
-            if (fused_chunk) {
-                nblk = pn2::ceil_div(rows, fused_chunk);   // written by the dgrad epilogue of layer i + 1
+            if (fused_nblk) {
+                nblk = fused_nblk;   // written by the dgrad epilogue (or the narrow backward kernel) of layer i + 1
             } else {
                 nblk = pn2::ceil_div(rows, RB);
                 const bool vec = (L.cout % 4 == 0) && (lddz % 4 == 0) && aligned16(dz) && aligned16(y);
@@ -811,14 +1048,42 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
             PN2_LAUNCH("bn_bwd_finalize", 8.0 * nblk * L.cout, 0, bn_bwd_finalize_kernel, dim3(L.cout), dim3(256), s,
                        (const float*)ws, nblk, rows, L.cout, L.stats, L.dgamma, L.dbeta);
             PN2_LAUNCH_CHECK();
-        } else if (L.dbias) {
+        } else if (L.dbias && !(narrow_ok(L, last, pool_k) && lddz == L.cout)) {
             const int nblk = pn2::ceil_div(rows, CS_ROWS);
             PN2_LAUNCH("colsum", 4.0 * rows * L.cout, 0, colsum_kernel, dim3(nblk), dim3(256), s, dz, lddz, rows, L.cout, ws);
-            PN2_LAUNCH("colsum_finalize", 4.0 * nblk * L.cout, 0, colsum_finalize_kernel, dim3(pn2::ceil_div(L.cout, 64)),
-                       dim3(64), s, (const float*)ws, nblk, L.cout, L.dbias);
+            PN2_LAUNCH("colsum_finalize", 4.0 * nblk * L.cout, 0, colsum_finalize_kernel, dim3(L.cout), dim3(64), s,
+                       (const float*)ws, nblk, L.cout, L.dbias);
             PN2_LAUNCH_CHECK();
         }
-        fused_chunk = 0;
+        fused_nblk = 0;
+        // layer input as an activation source
+        Act in = i == 0 ? Act{x, ldx, nullptr, 0}
+                        : Act{layers[i - 1].y, layers[i - 1].cout, layers[i - 1].has_bn ? layers[i - 1].stats : nullptr,
+                              layers[i - 1].relu};
+        // ---- narrow last layer: one vector-ALU pass does dgrad, wgrad, bias sums and the previous layer's BN sums
+        if (narrow_ok(L, last, pool_k) && lddz == L.cout && in.ld % 4 == 0 && aligned16(in.p)) {
+            const int nblk = pn2::ceil_div(rows, NR_ROWS);
+            float* part_s = ws;
+            float* part_w = part_s + (size_t)nblk * 2 * L.cin;
+            float* part_b = part_w + (size_t)nblk * L.cout * L.cin;
+            float* target = i > 0 ? bufs[which] : (dx ? dx : bufs[which]);
+            if (i == 0 && dx && lddx != L.cin) return PN2_E_BADARG;
+            int st = launch_narrow_bwd(in, rows, L, dz, target, part_s, part_w, part_b, s);
+            if (st) return st;
+            if (L.dweight)
+                PN2_LAUNCH("slab_reduce", 4.0 * (nblk + 2) * L.cout * L.cin, 0, slab_reduce_kernel,
+                           dim3(grid1d((long long)L.cout * L.cin)), dim3(256), s, (const float*)part_w, nblk,
+                           (long long)L.cout * L.cin, L.dweight);
+            if (L.dbias)
+                PN2_LAUNCH("colsum_finalize", 4.0 * nblk * L.cout, 0, colsum_finalize_kernel, dim3(L.cout), dim3(64), s,
+                           (const float*)part_b, nblk, L.cout, L.dbias);
+            PN2_LAUNCH_CHECK();
+            if (i > 0 && layers[i - 1].has_bn) fused_nblk = nblk;
+            dz = target;
+            lddz = L.cin;
+            which ^= 1;
+            continue;
+        }
         // dY operand (through BatchNorm+ReLU backward when the layer has one)
         Operand dy = plain(dz, lddz, rows, L.cout);
         if (L.has_bn) {
@@ -828,10 +1093,6 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
             dy.cstride = L.cout;
             dy.relu = L.relu;
         }
-        // layer input as an activation source
-        Act in = i == 0 ? Act{x, ldx, nullptr, 0}
-                        : Act{layers[i - 1].y, layers[i - 1].cout, layers[i - 1].has_bn ? layers[i - 1].stats : nullptr,
-                              layers[i - 1].relu};
         // ---- wgrad: dW[cout][cin] += dY^T X, reduction over rows split across blocks
         if (L.dweight) {
             const WgradPlan wp = plan_wgrad(rows, L.cout, L.cin);
@@ -878,7 +1139,7 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
                 g.ldey = layers[i - 1].cout;
                 g.ecoef = layers[i - 1].stats;
                 g.erelu = layers[i - 1].relu;
-                fused_chunk = tile / 2;
+                fused_nblk = pn2::ceil_div(rows, tile / 2);
             }
             int st = L.has_bn ? launch_gemm<true, TR_DY, false, TR_PLAIN, EPI_STORE>(g, 1, tile, s)
                               : launch_gemm<true, TR_PLAIN, false, TR_PLAIN, EPI_STORE>(g, 1, tile, s);

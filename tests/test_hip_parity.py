@@ -505,3 +505,35 @@ def test_forward_hierarchical_streaming_golden(pn2):
     visited = np.zeros(n, bool)
     visited[np.concatenate(rasters)] = True
     assert float(pred["offset_predictions"][torch.from_numpy(~visited).cuda()].abs().max()) == 0.0
+
+
+def test_get_loss_matches_compacted_form(pn2):
+    """The sync-free masked loss of PointNet2.get_loss equals point_wise_loss on the compacted rows (the reference's
+    formulation, PointNet2.py:180-207) for values and for the gradients w.r.t. the predictions."""
+    from pn2_amd.PointNet2.PointNet2 import PointNet2
+    from pn2_amd.Loss import point_wise_loss
+    torch.manual_seed(3)
+    B, N = 3, 500
+    model = PointNet2(depth=5, loss_multiplier_semantic=0.7, loss_multiplier_offset=1.3)
+    pad = torch.rand(B, N) > 0.3
+    pad[2, :] = False                                           # a fully padded sample
+    n_valid = int(pad.sum())
+    moff = torch.rand(n_valid) > 0.4
+    sem_lab = torch.randint(0, 2, (n_valid,))
+    off_lab = torch.randn(int(moff.sum()), 3)
+    outs = []
+    for masked in (True, False):
+        sem = torch.randn(B, 2, N, generator=torch.Generator().manual_seed(1)).cuda().requires_grad_(True)
+        off = torch.randn(B, 3, N, generator=torch.Generator().manual_seed(2)).cuda().requires_grad_(True)
+        mo = {"semantic_prediction_logits": sem, "offset_predictions": off}
+        if masked:
+            loss, ld = model.get_loss(mo, sem_lab.cuda(), off_lab.cuda(), moff.cuda(), pad.cuda())
+        else:
+            s_v, o_v = model._valid_rows(sem, off, pad.cuda(), moff.cuda())
+            ls, lo = point_wise_loss(s_v.float(), o_v.float(), sem_lab.cuda(), off_lab.cuda())
+            loss = ls * 0.7 + lo * 1.3
+        loss.backward()
+        outs.append((float(loss), sem.grad.cpu(), off.grad.cpu()))
+    assert abs(outs[0][0] - outs[1][0]) <= 1e-6 * abs(outs[1][0])
+    np.testing.assert_allclose(outs[0][1].numpy(), outs[1][1].numpy(), rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(outs[0][2].numpy(), outs[1][2].numpy(), rtol=1e-5, atol=1e-9)
