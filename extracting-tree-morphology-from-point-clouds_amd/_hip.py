@@ -46,7 +46,8 @@ SIGNATURES = {
     "pn2_gather_grad_f32": (_int, [_vp, _vp, _int, _int, _int, _int, _vp, _vp]),
     "pn2_three_nn_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _int, _int, _int, _vp, _vp, _vp, _vp]),
     "pn2_three_interpolate_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _int, _int, _int, _int, _vp, _i64, _i64, _vp]),
-    "pn2_three_interpolate_grad_f32": (_int, [_vp, _i64, _i64, _vp, _vp, _int, _int, _int, _int, _vp, _vp]),
+    "pn2_three_interpolate_grad_workspace_bytes": (_sz, [_int, _int, _int, _int]),
+    "pn2_three_interpolate_grad_f32": (_int, [_vp, _i64, _i64, _vp, _vp, _int, _int, _int, _int, _vp, _vp, _sz, _vp]),
     "pn2_prof_enable": (None, [_int]),
     "pn2_prof_collect": (_int, [ctypes.c_char_p, _sz, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong),
                                 ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _int]),

@@ -123,10 +123,136 @@ __global__ __launch_bounds__(kBlock) void three_interpolate_kernel(const float* 
     }
 }
 
-__global__ __launch_bounds__(kBlock) void three_interpolate_grad_kernel(const float* __restrict__ dout, int64_t out_stride,
-                                                                        int64_t out_offset, const int32_t* __restrict__ idx,
-                                                                        const float* __restrict__ w, int N, int S, int D,
-                                                                        float* __restrict__ dpoints2, long long total) {
+// Backward of the interpolation: dpoints2[b][idx[n][k]][c] += w[n][k] * dout[n][c].  ~768 dense points feed every
+// sampled point at FP1; issued as 3*N*D float atomics (100 M of them onto 512 KB) the op runs at the memory-side
+// atomic rate (0.5 ms), and LDS float atomics are no better (~2.6 LDS cycles per LANE, measured).  So the
+// contributions are first bucketed by destination (counting sort of the 3*N (point, weight) pairs: integer atomics
+// only), then one wavefront per 64-entry chunk of a destination's list sums the rows it names -- coalesced 512-byte
+// row reads, registers for the running sum -- and issues ONE float atomic row per chunk (64x fewer atomics).
+// Histogram of destinations.  Integer atomics on ~1000 hot global addresses serialise at ~235 ns each, so every
+// workgroup first counts its contiguous share of one cloud's pairs in LDS and then adds S totals to global memory.
+// blockIdx.y = cloud, blockIdx.x = share.
+constexpr int TIG_T = 1024;
+__global__ __launch_bounds__(TIG_T) void tig_count_kernel(const int32_t* __restrict__ idx, int N, int S, int per_block,
+                                                          int* __restrict__ hist) {
+    extern __shared__ int lh[];  // [S]
+    const int b = blockIdx.y;
+    for (int e = threadIdx.x; e < S; e += TIG_T) lh[e] = 0;
+    __syncthreads();
+    const long long p0 = (long long)blockIdx.x * per_block, p1 = p0 + per_block < 3LL * N ? p0 + per_block : 3LL * N;
+    const int32_t* ib = idx + (long long)b * 3 * N;
+    for (long long e = p0 + threadIdx.x; e < p1; e += TIG_T) atomicAdd(&lh[ib[e]], 1);
+    __syncthreads();
+    for (int e = threadIdx.x; e < S; e += TIG_T)
+        if (lh[e]) atomicAdd(hist + (long long)b * S + e, lh[e]);
+}
+
+// exclusive scans over hist[0..total) (one block; total = B*S is a few thousand): offs = list offsets (cursor starts
+// as a copy), coffs = offsets in units of 64-entry chunks (what the reduce kernel's wavefronts index)
+constexpr int TIG_CHUNK = 64;
+__global__ __launch_bounds__(1024) void tig_scan_kernel(const int* __restrict__ hist, int total, int* __restrict__ offs,
+                                                        int* __restrict__ cursor, int* __restrict__ coffs) {
+    __shared__ int part[1024], cpart[1024];
+    const int t = threadIdx.x;
+    const int per = (total + 1023) / 1024;
+    int sum = 0, csum = 0;
+    for (int k = 0; k < per; ++k) {
+        const int e = t * per + k;
+        if (e < total) {
+            sum += hist[e];
+            csum += (hist[e] + TIG_CHUNK - 1) / TIG_CHUNK;
+        }
+    }
+    part[t] = sum;
+    cpart[t] = csum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = t >= off ? part[t - off] : 0, cv = t >= off ? cpart[t - off] : 0;
+        __syncthreads();
+        part[t] += v;
+        cpart[t] += cv;
+        __syncthreads();
+    }
+    int run = t > 0 ? part[t - 1] : 0, crun = t > 0 ? cpart[t - 1] : 0;
+    for (int k = 0; k < per; ++k) {
+        const int e = t * per + k;
+        if (e < total) {
+            offs[e] = run;
+            cursor[e] = run;
+            coffs[e] = crun;
+            run += hist[e];
+            crun += (hist[e] + TIG_CHUNK - 1) / TIG_CHUNK;
+        }
+    }
+    if (t == 1023) {
+        offs[total] = part[1023];
+        coffs[total] = cpart[1023];
+    }
+}
+
+// Scatter the (row, weight) pairs into their destination's list: the workgroup counts its share in LDS again,
+// reserves one contiguous range per destination with a single returning global atomic, then ranks its pairs inside
+// that range with LDS atomics.
+__global__ __launch_bounds__(TIG_T) void tig_fill_kernel(const int32_t* __restrict__ idx, const float* __restrict__ w, int N,
+                                                         int S, int per_block, int* __restrict__ cursor,
+                                                         int2* __restrict__ list) {
+    extern __shared__ int lh[];  // [S] counts, then [S] running positions
+    const int b = blockIdx.y;
+    for (int e = threadIdx.x; e < S; e += TIG_T) lh[e] = 0;
+    __syncthreads();
+    const long long p0 = (long long)blockIdx.x * per_block, p1 = p0 + per_block < 3LL * N ? p0 + per_block : 3LL * N;
+    const int32_t* ib = idx + (long long)b * 3 * N;
+    const float* wb = w + (long long)b * 3 * N;
+    for (long long e = p0 + threadIdx.x; e < p1; e += TIG_T) atomicAdd(&lh[ib[e]], 1);
+    __syncthreads();
+    for (int e = threadIdx.x; e < S; e += TIG_T) {
+        const int c = lh[e];
+        lh[e] = c ? atomicAdd(cursor + (long long)b * S + e, c) : 0;   // base of this workgroup's range
+    }
+    __syncthreads();
+    for (long long e = p0 + threadIdx.x; e < p1; e += TIG_T) {
+        const int pos = atomicAdd(&lh[ib[e]], 1);
+        list[pos] = make_int2((int)((long long)b * N + e / 3), __float_as_int(wb[e]));
+    }
+}
+
+// one wavefront per 64-entry chunk of a destination's list; lane l owns channels l, l + 64, ... of the row
+__global__ __launch_bounds__(kBlock) void tig_reduce_kernel(const float* __restrict__ dout, int64_t out_stride, int64_t out_offset,
+                                                            const int* __restrict__ offs, const int* __restrict__ coffs,
+                                                            const int2* __restrict__ list, int BS, int D,
+                                                            float* __restrict__ dpoints2) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)));
+    if (wave >= coffs[BS]) return;
+    int lo_d = 0, hi_d = BS;  // destination with coffs[dest] <= wave < coffs[dest + 1]
+    while (hi_d - lo_d > 1) {
+        const int mid = (lo_d + hi_d) >> 1;
+        if (coffs[mid] <= wave) lo_d = mid; else hi_d = mid;
+    }
+    const int dest = lo_d;
+    const int lo = offs[dest] + (wave - coffs[dest]) * TIG_CHUNK, end = offs[dest + 1];
+    const int hi = lo + TIG_CHUNK < end ? lo + TIG_CHUNK : end;
+    for (int c0 = 0; c0 < D; c0 += 128) {
+        float a0 = 0.0f, a1 = 0.0f;
+        const int ca = c0 + lane, cb = c0 + 64 + lane;
+        for (int e = lo; e < hi; ++e) {
+            const int2 it = list[e];
+            const float ww = __int_as_float(it.y);
+            const float* row = dout + (long long)it.x * out_stride + out_offset;
+            if (ca < D) a0 += __fmul_rn(row[ca], ww);
+            if (cb < D) a1 += __fmul_rn(row[cb], ww);
+        }
+        float* dst = dpoints2 + (long long)dest * D;
+        if (ca < D) atomicAdd(dst + ca, a0);
+        if (cb < D) atomicAdd(dst + cb, a1);
+    }
+}
+
+// fallback for sampled sets too large for an LDS slice: plain global atomics
+__global__ __launch_bounds__(kBlock) void three_interpolate_grad_global_kernel(const float* __restrict__ dout, int64_t out_stride,
+                                                                               int64_t out_offset, const int32_t* __restrict__ idx,
+                                                                               const float* __restrict__ w, int N, int S, int D,
+                                                                               float* __restrict__ dpoints2, long long total) {
     for (long long e = (long long)blockIdx.x * kBlock + threadIdx.x; e < total; e += (long long)gridDim.x * kBlock) {
         const long long r = e / D;
         const int c = (int)(e - r * D);
@@ -206,16 +332,59 @@ extern "C" int pn2_three_interpolate_f32(const float* points2, int64_t pb, int64
     return 0;
 }
 
+// bucketing pays off once the op is large; below this many atomics the direct kernel is faster
+static bool tig_sorted(int B, int N, int S, int D) { return (long long)B * N * D >= (1LL << 22) && S <= 8192 && B <= 65535; }
+
+extern "C" size_t pn2_three_interpolate_grad_workspace_bytes(int B, int N, int S, int D) {
+    if (B <= 0 || N <= 0 || S <= 0 || D <= 0 || !tig_sorted(B, N, S, D)) return 16;
+    // hist, offs (+1), cursor: ints; list: (row, weight) pairs
+    return (size_t)(4 * ((size_t)B * S + 4)) * sizeof(int) + 16 + (size_t)B * N * 3 * sizeof(int2);
+}
+
 extern "C" int pn2_three_interpolate_grad_f32(const float* dout, int64_t out_stride, int64_t out_offset,
                                               const int32_t* idx, const float* w, int B, int N, int S, int D,
-                                              float* dpoints2, void* stream) {
+                                              float* dpoints2, void* workspace, size_t workspace_bytes, void* stream) {
     if (!dout || !idx || !w || !dpoints2 || B <= 0 || N <= 0 || S <= 0 || D <= 0 || out_stride < out_offset + D)
         return PN2_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     PN2_HIP_CHECK(hipMemsetAsync(dpoints2, 0, (size_t)B * S * D * sizeof(float), s));
-    const long long total = (long long)B * N * D;
-    PN2_LAUNCH("three_interpolate_grad", (double)B * N * (36.0 + 4.0 * D) + 4.0 * B * S * D, 0, three_interpolate_grad_kernel,
-               dim3(grid_for(total)), dim3(kBlock), s, dout, out_stride, out_offset, idx, w, N, S, D, dpoints2, total);
+    const double bytes = (double)B * N * (36.0 + 4.0 * D) + 4.0 * B * S * D;
+    if (!tig_sorted(B, N, S, D)) {
+        const long long total = (long long)B * N * D;
+        PN2_LAUNCH("three_interpolate_grad", bytes, 0, three_interpolate_grad_global_kernel, dim3(grid_for(total)), dim3(kBlock), s,
+                   dout, out_stride, out_offset, idx, w, N, S, D, dpoints2, total);
+        PN2_LAUNCH_CHECK();
+        return 0;
+    }
+    if (!workspace || workspace_bytes < pn2_three_interpolate_grad_workspace_bytes(B, N, S, D)) return PN2_E_WORKSPACE;
+    const int BS = B * S;
+    int* hist = (int*)workspace;
+    int* offs = hist + BS + 4;
+    int* cursor = offs + BS + 4;
+    int* coffs = cursor + BS + 4;
+    int2* list = (int2*)(((uintptr_t)(coffs + BS + 4) + 15) & ~(uintptr_t)15);
+    const long long pairs = (long long)B * N * 3;
+    PN2_HIP_CHECK(hipMemsetAsync(hist, 0, (size_t)(BS + 4) * sizeof(int), s));
+    // ~64 workgroups per launch keep the per-destination global atomics few; S ints of LDS each
+    int shares = 64 / B;
+    if (shares < 1) shares = 1;
+    int per_block = pn2::ceil_div(pn2::ceil_div(3LL * N, shares), TIG_T) * TIG_T;
+    shares = pn2::ceil_div(3LL * N, per_block);
+    const size_t lds = (size_t)S * sizeof(int);
+    {
+        pn2::prof::Scope sc_("tig_count", s, 8.0 * pairs, 0);
+        hipLaunchKernelGGL(tig_count_kernel, dim3(shares, B), dim3(TIG_T), lds, s, idx, N, S, per_block, hist);
+    }
+    PN2_LAUNCH("tig_scan", 12.0 * BS, 0, tig_scan_kernel, dim3(1), dim3(1024), s, (const int*)hist, BS, offs, cursor, coffs);
+    {
+        pn2::prof::Scope sc_("tig_fill", s, 24.0 * pairs, 0);
+        hipLaunchKernelGGL(tig_fill_kernel, dim3(shares, B), dim3(TIG_T), lds, s, idx, w, N, S, per_block, cursor, list);
+    }
+    // sum over destinations of ceil(len / 64) <= pairs / 64 + B*S: wavefronts beyond the real chunk count exit at once
+    const long long waves = pairs / TIG_CHUNK + BS + 1;
+    if (waves > 0x7FFFFFFFLL / 64) return PN2_E_BADARG;
+    PN2_LAUNCH("three_interpolate_grad", bytes, 0, tig_reduce_kernel, dim3((unsigned)pn2::ceil_div(waves, kBlock / 64)), dim3(kBlock),
+               s, dout, out_stride, out_offset, (const int*)offs, (const int*)coffs, (const int2*)list, BS, D, dpoints2);
     PN2_LAUNCH_CHECK();
     return 0;
 }

@@ -208,7 +208,9 @@ class ThreeInterpolateConcat(torch.autograd.Function):
         d2 = None
         if ctx.needs_input_grad[1]:
             d2 = torch.empty(B, S, D2, dtype=torch.float32, device=dout.device)
-            _hip.call("three_interpolate_grad", _hip.lib().pn2_three_interpolate_grad_f32, dout.data_ptr(), D1 + D2, D1,
-                      idx32.data_ptr(), w.data_ptr(), B, N, S, D2, d2.data_ptr(), _hip.stream_ptr(),
+            lib = _hip.lib()
+            ws = _workspace(lib.pn2_three_interpolate_grad_workspace_bytes(B, N, S, D2), dout.device)
+            _hip.call("three_interpolate_grad", lib.pn2_three_interpolate_grad_f32, dout.data_ptr(), D1 + D2, D1,
+                      idx32.data_ptr(), w.data_ptr(), B, N, S, D2, d2.data_ptr(), ws.data_ptr(), ws.numel(), _hip.stream_ptr(),
                       nbytes=B * N * (3 * 12 + 4 * D2) + 4 * B * S * D2)
         return d1, d2, None, None

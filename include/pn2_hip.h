@@ -108,10 +108,13 @@ int pn2_three_nn_f32(const float *xyz1, int64_t ab, int64_t an, int64_t ac, cons
 int pn2_three_interpolate_f32(const float *points2, int64_t pb, int64_t pn, int64_t pc, const int32_t *idx,
                               const float *w, int B, int N, int S, int D, float *out, int64_t out_stride,
                               int64_t out_offset, void *stream);
-/* dpoints2 [B,S,D] (dense, zeroed by the call) += w * dout[:, out_offset : out_offset+D] */
+/* dpoints2 [B,S,D] (dense, zeroed by the call) += w * dout[:, out_offset : out_offset+D]
+ * workspace: pn2_three_interpolate_grad_workspace_bytes(B,N,S,D) bytes (large calls bucket the contributions by
+ * destination before summing them). */
+size_t pn2_three_interpolate_grad_workspace_bytes(int B, int N, int S, int D);
 int pn2_three_interpolate_grad_f32(const float *dout, int64_t out_stride, int64_t out_offset,
                                    const int32_t *idx, const float *w, int B, int N, int S, int D,
-                                   float *dpoints2, void *stream);
+                                   float *dpoints2, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Pointwise MLP chains: (1x1 conv -> BatchNorm -> ReLU) x n [-> max over groups of pool_k rows]
