@@ -24,6 +24,7 @@
 namespace {
 
 using u64 = unsigned long long;
+using f2 = __attribute__((ext_vector_type(2))) float;
 constexpr u64 kValid = 1ull << 63;
 constexpr int kMaxG = 64;
 constexpr unsigned kSpinLimit = 1u << 22;
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
 // (plain-store granules); if no XCD holds G workgroups (busy GPU, odd placement) the launch falls back, as a
 // whole, to groups of consecutive block ids with the placement-independent write-through granules.  Either way
 // results are identical; only the speed depends on placement.
-constexpr int kXT = 1024, kXPPT = 8, kXGrid = 256;
+constexpr int kXT = 512, kXPPT = 16, kXGrid = 256;
 struct XcdHeader {
     unsigned err, arrived, cnt[8], pad[6];
 };
@@ -268,6 +269,9 @@ __global__ __launch_bounds__(kXT) void fps_xcd_kernel(const float* __restrict__ 
     __shared__ u64 s_win[2];
     __shared__ float s_wxyz[2][3];
     __shared__ int s_role[4];  // {group id or -1, rank in group, number of groups, local?}
+    // the workgroup's points once more in LDS: the lane that wins a step fetches its coordinates from here instead
+    // of every thread dragging (x, y, z) of its running best through the update loop
+    __shared__ float s_px[kXPPT * kXT], s_py[kXPPT * kXT], s_pz[kXPPT * kXT];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
@@ -324,16 +328,21 @@ __global__ __launch_bounds__(kXT) void fps_xcd_kernel(const float* __restrict__ 
 
     for (int b = group; b < B; b += ngroups) {
         const float* p = xyz + (int64_t)b * sb;
-        float x[kXPPT], y[kXPPT], z[kXPPT], d[kXPPT];
+        // two points per register pair: the subtract / multiply / add of the update run as packed fp32 ops
+        f2 x[kXPPT / 2], y[kXPPT / 2], z[kXPPT / 2], d[kXPPT / 2];
 #pragma unroll
         for (int j = 0; j < kXPPT; ++j) {
             const int n = base + j * T;
             const bool ok = j < ppt && n < N;
             const float* q = p + (int64_t)(ok ? n : 0) * sn;
-            x[j] = q[0];
-            y[j] = q[sc];
-            z[j] = q[2 * sc];
-            d[j] = ok ? 1e10f : -1.0f;
+            const float qx = q[0], qy = q[sc], qz = q[2 * sc];
+            x[j >> 1][j & 1] = qx;
+            y[j >> 1][j & 1] = qy;
+            z[j >> 1][j & 1] = qz;
+            d[j >> 1][j & 1] = ok ? 1e10f : -1.0f;
+            s_px[j * T + tid] = qx;
+            s_py[j * T + tid] = qy;
+            s_pz[j * T + tid] = qz;
         }
         int far = (int)start[b];
         float cx, cy, cz;
@@ -364,19 +373,23 @@ __global__ __launch_bounds__(kXT) void fps_xcd_kernel(const float* __restrict__ 
             }
             if (i == npoint - 1) break;
 
-            float bestd = -1.0f, bx = 0.f, by = 0.f, bz = 0.f;
+            float bestd = -1.0f;
             int bestj = 0;
+            const f2 c2x = {cx, cx}, c2y = {cy, cy}, c2z = {cz, cz};
 #pragma unroll
-            for (int j = 0; j < kXPPT; ++j) {
-                const float dx = __fsub_rn(x[j], cx), dy = __fsub_rn(y[j], cy), dz = __fsub_rn(z[j], cz);
-                const float dist = pn2::norm2(dx, dy, dz);
-                d[j] = dist < d[j] ? dist : d[j];
-                if (d[j] > bestd) {
-                    bestd = d[j];
-                    bestj = j;
-                    bx = x[j];
-                    by = y[j];
-                    bz = z[j];
+            for (int q = 0; q < kXPPT / 2; ++q) {
+                // ((dx*dx + dy*dy) + dz*dz), unfused (the TU is built with -ffp-contract=off), two points at a time
+                const f2 dx = x[q] - c2x, dy = y[q] - c2y, dz = z[q] - c2z;
+                const f2 dist = (dx * dx + dy * dy) + dz * dz;
+                d[q][0] = fminf(d[q][0], dist[0]);   // slots beyond N hold -1 and stay -1
+                d[q][1] = fminf(d[q][1], dist[1]);
+                if (d[q][0] > bestd) {  // strict: the lowest index of this thread wins
+                    bestd = d[q][0];
+                    bestj = 2 * q;
+                }
+                if (d[q][1] > bestd) {
+                    bestd = d[q][1];
+                    bestj = 2 * q + 1;
                 }
             }
             const int bestn = base + bestj * T;
@@ -387,9 +400,9 @@ __global__ __launch_bounds__(kXT) void fps_xcd_kernel(const float* __restrict__ 
             const u64 owners = __ballot(mykey == wkey);
             if (lane == (int)__builtin_ctzll(owners)) {
                 s_key[buf][wave] = wkey;
-                s_xyz[buf][wave][0] = bx;
-                s_xyz[buf][wave][1] = by;
-                s_xyz[buf][wave][2] = bz;
+                s_xyz[buf][wave][0] = s_px[bestj * T + tid];
+                s_xyz[buf][wave][1] = s_py[bestj * T + tid];
+                s_xyz[buf][wave][2] = s_pz[bestj * T + tid];
             }
             STAMP(0);
             lds_barrier();
