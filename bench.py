@@ -22,6 +22,26 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 from __graft_entry__ import load_pkg  # noqa: E402
 
+# library kernel name -> substring of the device kernel name in the PMC traffic summary (tools/pmc_traffic.py)
+PMC_NAMES = {"fps": "fps_xcd_kernel", "gemm_fwd": "gemm_kernel<true, 1, true, 0, 0, 128", "gemm_dgrad": "gemm_kernel<true, 2, false, 0, 1, 128",
+             "gemm_wgrad": "gemm_kernel<false, 2, false, 1, 2, 128", "three_interpolate_grad": "tig_reduce_kernel",
+             "ball_query": "ball_query_kernel", "three_nn": "three_nn_kernel", "narrow_bwd": "narrow_bwd_kernel",
+             "narrow_fwd": "narrow_fwd_kernel"}
+PMC_FILE = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
+    command (separate passes, gfx950 corrections as in tools/pmc_traffic.py); None when not collected."""
+    try:
+        table = json.load(open(PMC_FILE))
+    except Exception:
+        return None
+    key = PMC_NAMES.get(kernel)
+    rows = [v for k, v in table.items() if key and key in k]
+    return max(r["traffic_bytes_per_launch"] for r in rows) if rows else None
+
+
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
 F32_MFMA_PEAK_TFLOPS = 157.3   # dense fp32-input MFMA peak
 
@@ -139,6 +159,7 @@ def main():
         else:
             roofline = {"kernel": dom["name"], "bound": "hbm", "achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": hbm / HBM_PEAK_GBS, "traffic": None}
+        roofline["traffic"] = pmc_traffic(dom["name"])
         roofline.update({"algorithmic_bytes_per_launch": dom["bytes"], "algorithmic_flops_per_launch": dom["flops"],
                          "avg_launch_us": 1e6 * avg_s, "launches_per_step": dom["calls"] / args.steps,
                          "share_of_step": dom["ms"] / args.steps / step_ms})
