@@ -131,7 +131,7 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
             const int bestn = base + bestj * T;
             const u64 mykey =
                 bestd < 0.0f ? 0ull : (((u64)__float_as_uint(bestd)) << 32) | (u64)(0xFFFFFFFFu - (unsigned)bestn);
-            const u64 wkey = pn2::wave_max_u64(mykey);
+            const u64 wkey = pn2::wave_max_key((unsigned)(mykey >> 32), (unsigned)mykey);
             const int buf = i & 1;
             // the lane that owns the wave maximum (keys are unique unless all are 0) publishes key + coordinates
             const u64 owners = __ballot(mykey == wkey);
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
                     }
                 } else {
                     const u64 cand = lane < NW ? s_key[buf][lane] : 0ull;
-                    k = pn2::wave_max_u64(cand);
+                    k = pn2::wave_max_key((unsigned)(cand >> 32), (unsigned)cand);
                     kw = (int)__builtin_ctzll(__ballot(lane < NW && cand == k));
                 }
                 nx = s_xyz[buf][kw][0];
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
                     }
                     STAMP(3);  // poll
                     const u64 mine = v0 & ~kValid;
-                    const u64 best = pn2::wave_max_u64(mine);
+                    const u64 best = pn2::wave_max_key((unsigned)(mine >> 32), (unsigned)mine);
                     const u64 own = __ballot(lane < G && mine == best);
                     if (lane == (int)__builtin_ctzll(own)) {
                         s_win[buf] = best;
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(kXT) void fps_xcd_kernel(const float* __restrict__ 
             const int bestn = base + bestj * T;
             const u64 mykey =
                 bestd < 0.0f ? 0ull : (((u64)__float_as_uint(bestd)) << 32) | (u64)(0xFFFFFFFFu - (unsigned)bestn);
-            const u64 wkey = pn2::wave_max_u64(mykey);
+            const u64 wkey = pn2::wave_max_key((unsigned)(mykey >> 32), (unsigned)mykey);
             const int buf = i & 1;
             const u64 owners = __ballot(mykey == wkey);
             if (lane == (int)__builtin_ctzll(owners)) {
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(kXT) void fps_xcd_kernel(const float* __restrict__ 
                     }
                 } else {
                     const u64 cand = lane < NW ? s_key[buf][lane] : 0ull;
-                    k = pn2::wave_max_u64(cand);
+                    k = pn2::wave_max_key((unsigned)(cand >> 32), (unsigned)cand);
                     kw = (int)__builtin_ctzll(__ballot(lane < NW && cand == k));
                 }
                 nx = s_xyz[buf][kw][0];
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(kXT) void fps_xcd_kernel(const float* __restrict__ 
                     }
                     STAMP(3);
                     const u64 mine = v0 & ~kValid;
-                    const u64 best = pn2::wave_max_u64(mine);
+                    const u64 best = pn2::wave_max_key((unsigned)(mine >> 32), (unsigned)mine);
                     const u64 own = __ballot(lane < G && mine == best);
                     if (lane == (int)__builtin_ctzll(own)) {
                         s_win[buf] = best;

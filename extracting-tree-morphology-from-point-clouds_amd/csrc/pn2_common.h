@@ -82,6 +82,36 @@ __device__ __forceinline__ unsigned long long dpp_max_step(unsigned long long v)
     return o > v ? o : v;
 }
 
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_u32(unsigned identity, unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)identity, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+    v = max(v, dpp_u32<0x111, 0xF>(0u, v));
+    v = max(v, dpp_u32<0x112, 0xF>(0u, v));
+    v = max(v, dpp_u32<0x114, 0xF>(0u, v));
+    v = max(v, dpp_u32<0x118, 0xF>(0u, v));
+    v = max(v, dpp_u32<0x142, 0xA>(0u, v));
+    v = max(v, dpp_u32<0x143, 0xC>(0u, v));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+    v = min(v, dpp_u32<0x111, 0xF>(0xFFFFFFFFu, v));
+    v = min(v, dpp_u32<0x112, 0xF>(0xFFFFFFFFu, v));
+    v = min(v, dpp_u32<0x114, 0xF>(0xFFFFFFFFu, v));
+    v = min(v, dpp_u32<0x118, 0xF>(0xFFFFFFFFu, v));
+    v = min(v, dpp_u32<0x142, 0xA>(0xFFFFFFFFu, v));
+    v = min(v, dpp_u32<0x143, 0xC>(0xFFFFFFFFu, v));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+// Wavefront max of the 64-bit key (hi << 32 | lo) as two 32-bit DPP reductions (each step is one v_max/v_min with a
+// DPP source): max of the high words, then max of the low words among the lanes that hold it.
+__device__ __forceinline__ unsigned long long wave_max_key(unsigned hi, unsigned lo) {
+    const unsigned mh = wave_max_u32(hi);
+    const unsigned ml = wave_max_u32(hi == mh ? lo : 0u);
+    return ((unsigned long long)mh << 32) | ml;
+}
+
 __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
     v = dpp_max_step<0x111, 0xF>(v);  // row_shr:1
     v = dpp_max_step<0x112, 0xF>(v);  // row_shr:2
