@@ -76,12 +76,13 @@ struct Stager {
     static constexpr int LD = TILE + 4;
     float4 v[NP], y[NP];
     float cm[4], cs[4], cb[4], ca[4], cq[4];
+    int tid;  // thread index inside the 256-thread team that stages this tile
 
     __device__ __forceinline__ int chan0(int o0, int k0) const {
-        return T_LAYOUT ? k0 + 4 * ((int)threadIdx.x % KT) : o0 + 4 * ((int)threadIdx.x % OQ);
+        return T_LAYOUT ? k0 + 4 * (tid % KT) : o0 + 4 * (tid % OQ);
     }
     __device__ __forceinline__ int row_of(int p, int o0, int k0) const {
-        return T_LAYOUT ? o0 + RPP * p + ((int)threadIdx.x / KT) : k0 + KPP * p + ((int)threadIdx.x / OQ);
+        return T_LAYOUT ? o0 + RPP * p + (tid / KT) : k0 + KPP * p + (tid / OQ);
     }
     __device__ __forceinline__ void load_coefs(const Operand& o, int c0) {
         if (KIND == TR_PLAIN) return;
@@ -150,11 +151,11 @@ struct Stager {
             w[j] = in ? xf(e[j], KIND == TR_DY ? yy[j] : 0.0f, j, o.relu) : 0.0f;
         }
         if (T_LAYOUT) {
-            const int m = RPP * p + ((int)threadIdx.x / KT), k = 4 * ((int)threadIdx.x % KT);
+            const int m = RPP * p + (tid / KT), k = 4 * (tid % KT);
 #pragma unroll
             for (int j = 0; j < 4; ++j) S[(k + j) * LD + m] = w[j];
         } else {
-            const int k = KPP * p + ((int)threadIdx.x / OQ), m = 4 * ((int)threadIdx.x % OQ);
+            const int k = KPP * p + (tid / OQ), m = 4 * (tid % OQ);
             *(float4*)(S + k * LD + m) = make_float4(w[0], w[1], w[2], w[3]);
         }
     }
@@ -182,11 +183,19 @@ struct GemmArgs {
 
 // TILE = 128: four waves own 64 x 64 each (2 x 2 MFMA accumulators); TILE = 64: 32 x 32 each (one accumulator),
 // for problems too small to fill the chip with 128-tiles.
-template <bool A_T, int A_KIND, bool B_T, int B_KIND, int EPI, int TILE, bool VEC>
-__global__ __launch_bounds__(NT, (EPI == EPI_STORE ? 2 : 3)) void gemm_kernel(const GemmArgs g) {
+// TEAMS = 4 (64-tiles only): the block holds four 256-thread teams that each contract a quarter of K into their own
+// accumulators and LDS buffers; the quarters are summed through LDS at the end.  Deep levels have GEMMs with a few
+// hundred rows and K up to 768: a handful of workgroups whose serial K loop is pure latency -- four teams put four
+// times the loads in flight and give every SIMD four waves to interleave.
+template <bool A_T, int A_KIND, bool B_T, int B_KIND, int EPI, int TILE, bool VEC, int TEAMS>
+__global__ __launch_bounds__(NT * TEAMS, (TEAMS > 1 ? 1 : (EPI == EPI_STORE ? 2 : 3))) void gemm_kernel(const GemmArgs g) {
     constexpr int LD = TILE + 4, WT = TILE / 2, NI = WT / 32;
-    __shared__ __attribute__((aligned(16))) float As[2][BK * LD];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK * LD];
+    static_assert(TEAMS == 1 || TILE == 64, "teams are for the small-problem tile");
+    // one LDS object (it is re-used as the teams' reduction buffer): [team][A|B][buffer][BK * LD]
+    __shared__ __attribute__((aligned(16))) float lds[TEAMS * 4 * BK * LD];
+    const int team = (int)threadIdx.x / NT, tid = (int)threadIdx.x % NT;
+    float(*As)[BK * LD] = (float(*)[BK * LD])(lds + (team * 4 + 0) * BK * LD);
+    float(*Bs)[BK * LD] = (float(*)[BK * LD])(lds + (team * 4 + 2) * BK * LD);
 
     const int m0 = blockIdx.x * TILE, n0 = blockIdx.y * TILE;
     int k_begin = 0, k_end = g.K;
@@ -194,7 +203,12 @@ __global__ __launch_bounds__(NT, (EPI == EPI_STORE ? 2 : 3)) void gemm_kernel(co
         k_begin = blockIdx.z * g.k_per_split;
         k_end = k_begin + g.k_per_split < g.K ? k_begin + g.k_per_split : g.K;
     }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int nk = (k_end - k_begin + BK - 1) / BK;
+    if (TEAMS > 1) {  // every team runs the same number of K-tiles (loads beyond K are zero-filled)
+        nk = (nk + TEAMS - 1) / TEAMS;
+        k_begin += team * nk * BK;
+    }
+    const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, half = lane >> 5;
 
     f32x16 acc[NI][NI];
@@ -207,9 +221,10 @@ __global__ __launch_bounds__(NT, (EPI == EPI_STORE ? 2 : 3)) void gemm_kernel(co
 
     Stager<A_T, A_KIND, TILE, VEC> sa;
     Stager<B_T, B_KIND, TILE, VEC> sb;
+    sa.tid = tid;
+    sb.tid = tid;
     sa.prepare(g.A, m0);
     sb.prepare(g.B, n0);
-    const int nk = (k_end - k_begin + BK - 1) / BK;
     if (nk > 0) {
         sa.fetch(g.A, m0, k_begin);
         sb.fetch(g.B, n0, k_begin);
@@ -253,6 +268,22 @@ __global__ __launch_bounds__(NT, (EPI == EPI_STORE ? 2 : 3)) void gemm_kernel(co
             }
         }
         __syncthreads();
+    }
+
+    if (TEAMS > 1) {
+        // sum the teams' partial tiles through LDS (the staging buffers are free now); team 0 runs the epilogue
+        float* red = lds;   // (TEAMS - 1) x NT x 16 floats = 48 KiB of the 68 KiB
+        static_assert(TEAMS == 1 || (TEAMS - 1) * 16 * NT <= TEAMS * 4 * BK * LD, "reduction buffer must fit");
+        if (team > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[((team - 1) * 16 + r) * NT + tid] = acc[0][0][r];
+        }
+        __syncthreads();
+        if (team > 0) return;
+#pragma unroll
+        for (int t = 0; t < TEAMS - 1; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][0][r] += red[(t * 16 + r) * NT + tid];
     }
 
     // ---- epilogue.  C/D layout of 32x32x2: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
@@ -827,6 +858,8 @@ Operand act_operand(const Act& a, int rows, int cols) {
     return o;
 }
 
+inline long long grid_blocks(int M, int N, int tile) { return (long long)pn2::ceil_div(M, tile) * pn2::ceil_div(N, tile); }
+
 // Tile choice: 128-tiles unless they would leave most of the chip idle (deep levels have a few hundred rows).
 inline int pick_tile(int M, int N, int nsplit) {
     if (M <= 64 || N <= 64) return 64;   // a narrow output (the 128 -> 2/3 head convs) wastes less of a 64-tile
@@ -834,13 +867,14 @@ inline int pick_tile(int M, int N, int nsplit) {
     return big >= 96 ? 128 : 64;
 }
 
-template <bool A_T, int A_KIND, bool B_T, int B_KIND, int EPI, int TILE, bool VEC>
+template <bool A_T, int A_KIND, bool B_T, int B_KIND, int EPI, int TILE, bool VEC, int TEAMS = 1>
 int launch_gemm_tv(GemmArgs& g, int nsplit, hipStream_t s) {
     dim3 grid(pn2::ceil_div(g.M, TILE), pn2::ceil_div(g.N, TILE), nsplit);
     const char* name = EPI == EPI_FWD ? "gemm_fwd" : EPI == EPI_STORE ? "gemm_dgrad" : "gemm_wgrad";
     const double mk = (double)g.M * g.K * (A_KIND == TR_DY ? 2 : 1), kn = (double)g.K * g.N * (B_KIND == TR_DY ? 2 : 1);
     const double bytes = 4.0 * (mk + kn + (double)g.M * g.N * (EPI == EPI_SLAB ? nsplit : 1));
-    PN2_LAUNCH(name, bytes, 2.0 * g.M * g.N * g.K, (gemm_kernel<A_T, A_KIND, B_T, B_KIND, EPI, TILE, VEC>), grid, dim3(NT), s, g);
+    PN2_LAUNCH(name, bytes, 2.0 * g.M * g.N * g.K, (gemm_kernel<A_T, A_KIND, B_T, B_KIND, EPI, TILE, VEC, TEAMS>), grid,
+               dim3(NT * TEAMS), s, g);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
@@ -851,6 +885,10 @@ int launch_gemm(GemmArgs& g, int nsplit, int tile, hipStream_t s) {
     if (tile == 128)
         return vec ? launch_gemm_tv<A_T, A_KIND, B_T, B_KIND, EPI, 128, true>(g, nsplit, s)
                    : launch_gemm_tv<A_T, A_KIND, B_T, B_KIND, EPI, 128, false>(g, nsplit, s);
+    // small problem with a long contraction: split K over four teams inside the workgroup
+    if (EPI != EPI_SLAB && g.K >= 8 * BK && (long long)grid_blocks(g.M, g.N, 64) <= 512)
+        return vec ? launch_gemm_tv<A_T, A_KIND, B_T, B_KIND, EPI, 64, true, 4>(g, nsplit, s)
+                   : launch_gemm_tv<A_T, A_KIND, B_T, B_KIND, EPI, 64, false, 4>(g, nsplit, s);
     return vec ? launch_gemm_tv<A_T, A_KIND, B_T, B_KIND, EPI, 64, true>(g, nsplit, s)
                : launch_gemm_tv<A_T, A_KIND, B_T, B_KIND, EPI, 64, false>(g, nsplit, s);
 }
