@@ -20,6 +20,8 @@
 //                                     dgrad    dX = dY W            (A rows x Cout, B = W as [K][N])
 //                                     wgrad    dW = dY^T X          (reduction over rows, split over blocks,
 //                                                                    fixed-order slab sum -> deterministic)
+#include <stdlib.h>
+
 #include "pn2_common.h"
 
 namespace {
@@ -66,13 +68,13 @@ __device__ __forceinline__ float4 ld4(const float* base, long long ld, int r, in
 // [k][outer]) tile: TILE/32 float4 per thread (+ as many for the second source) and the BatchNorm coefficients
 // of the thread's 4 channels in registers.  The channel is always the contiguous global index: k for the T
 // layout (reloaded per K-tile), the outer index for the D layout (loaded once).
-template <bool T_LAYOUT, int KIND, int TILE, bool VEC>
+template <bool T_LAYOUT, int KIND, int TILE, bool VEC, int THREADS = NT>
 struct Stager {
-    static constexpr int NP = TILE * BK / (4 * NT);   // 16-byte loads per thread per K-tile
+    static constexpr int NP = TILE * BK / (4 * THREADS);   // 16-byte loads per thread per K-tile
     static constexpr int KT = BK / 4;        // T layout: threads along k per row
-    static constexpr int RPP = NT / KT;      // T layout: rows per pass
+    static constexpr int RPP = THREADS / KT; // T layout: rows per pass
     static constexpr int OQ = TILE / 4;      // D layout: threads per k-row
-    static constexpr int KPP = NT / OQ;      // D layout: k-rows per pass
+    static constexpr int KPP = THREADS / OQ; // D layout: k-rows per pass
     static constexpr int LD = TILE + 4;
     float4 v[NP], y[NP];
     float cm[4], cs[4], cb[4], ca[4], cq[4];
@@ -183,6 +185,87 @@ struct GemmArgs {
 
 // TILE = 128: four waves own 64 x 64 each (2 x 2 MFMA accumulators); TILE = 64: 32 x 32 each (one accumulator),
 // for problems too small to fill the chip with 128-tiles.
+// Epilogue shared by the GEMM kernels: the wave owns NI x NI 32x32 accumulators whose top-left element is
+// (row0, col0); chunk_rows = rows covered by one wave (= one statistics chunk).
+template <int EPI, int NI>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[NI][NI], int row0, int col0, int chunk_rows,
+                                              int lane, int split) {
+    const int l31 = lane & 31, half = lane >> 5;
+    const int m0 = row0, wm = 0, WT = chunk_rows, n0 = col0, wn = 0;   // names used by the body below
+    (void)wm; (void)wn;
+    // ---- epilogue.  C/D layout of 32x32x2: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    float* C = g.C;
+    if (EPI == EPI_SLAB) C += (long long)split * g.M * g.ldc;
+    const int rbase = m0 + wm * WT + 4 * half;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int col = n0 + wn * WT + 32 * j + l31;
+        const bool cok = col < g.N;
+        const float bias = (EPI == EPI_FWD && g.bias && cok) ? g.bias[col] : 0.0f;
+        float sum = 0.0f;
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rbase + 32 * i + (r & 3) + 8 * (r >> 2);
+                const float val = acc[i][j][r] + bias;
+                acc[i][j][r] = val;
+                if (row < g.M) {
+                    if (cok) C[(long long)row * g.ldc + col] = val;
+                    sum += val;
+                    ++cnt;
+                }
+            }
+        // per-(row chunk of WT rows, column) partials; the other half-wave holds the other rows of the column
+        const long long chunk = (m0 + wm * WT) / WT;
+        if (EPI == EPI_FWD && g.partial) {
+            sum += __shfl_xor(sum, 32, 64);
+            cnt += __shfl_xor(cnt, 32, 64);
+            const float mean = cnt > 0 ? sum / (float)cnt : 0.0f;
+            float m2 = 0.0f;
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + 32 * i + (r & 3) + 8 * (r >> 2);
+                    const float d = acc[i][j][r] - mean;
+                    if (row < g.M) m2 += d * d;
+                }
+            m2 += __shfl_xor(m2, 32, 64);
+            if (half == 0 && cok && m0 + wm * WT < g.M) {
+                g.partial[(chunk * 2 + 0) * g.N + col] = mean;
+                g.partial[(chunk * 2 + 1) * g.N + col] = m2;
+            }
+        }
+        if (EPI == EPI_STORE && g.partial) {
+            // BatchNorm-backward sums of the layer whose dZ this tile is: s1 = sum mask*dz, s2 = sum mask*dz*xhat
+            const int cc = cok ? col : 0;
+            const float mean = g.ecoef[ST_MEAN * g.N + cc], sc = g.ecoef[ST_SCALE * g.N + cc];
+            const float bt = g.ecoef[ST_BETA * g.N + cc], invstd = g.ecoef[ST_INVSTD * g.N + cc];
+            float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + 32 * i + (r & 3) + 8 * (r >> 2);
+                    const int rr = row < g.M ? row : g.M - 1;
+                    const float yy = g.ey[(long long)rr * g.ldey + cc];
+                    const float t = __builtin_fmaf(yy - mean, sc, bt);
+                    const float dzh = (row < g.M && (!g.erelu || t > 0.0f)) ? acc[i][j][r] : 0.0f;
+                    s1 += dzh;
+                    s2 += dzh * ((yy - mean) * invstd);
+                }
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (half == 0 && cok && m0 + wm * WT < g.M) {
+                g.partial[(chunk * 2 + 0) * g.N + col] = s1;
+                g.partial[(chunk * 2 + 1) * g.N + col] = s2;
+            }
+        }
+    }
+}
+
 // TEAMS = 4 (64-tiles only): the block holds four 256-thread teams that each contract a quarter of K into their own
 // accumulators and LDS buffers; the quarters are summed through LDS at the end.  Deep levels have GEMMs with a few
 // hundred rows and K up to 768: a handful of workgroups whose serial K loop is pure latency -- four teams put four
@@ -286,77 +369,7 @@ __global__ __launch_bounds__(NT * TEAMS, (TEAMS > 1 ? 1 : (EPI == EPI_STORE ? 2 
             for (int r = 0; r < 16; ++r) acc[0][0][r] += red[(t * 16 + r) * NT + tid];
     }
 
-    // ---- epilogue.  C/D layout of 32x32x2: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-    float* C = g.C;
-    if (EPI == EPI_SLAB) C += (long long)blockIdx.z * g.M * g.ldc;
-    const int rbase = m0 + wm * WT + 4 * half;
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        const int col = n0 + wn * WT + 32 * j + l31;
-        const bool cok = col < g.N;
-        const float bias = (EPI == EPI_FWD && g.bias && cok) ? g.bias[col] : 0.0f;
-        float sum = 0.0f;
-        int cnt = 0;
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rbase + 32 * i + (r & 3) + 8 * (r >> 2);
-                const float val = acc[i][j][r] + bias;
-                acc[i][j][r] = val;
-                if (row < g.M) {
-                    if (cok) C[(long long)row * g.ldc + col] = val;
-                    sum += val;
-                    ++cnt;
-                }
-            }
-        // per-(row chunk of WT rows, column) partials; the other half-wave holds the other rows of the column
-        const long long chunk = (m0 + wm * WT) / WT;
-        if (EPI == EPI_FWD && g.partial) {
-            sum += __shfl_xor(sum, 32, 64);
-            cnt += __shfl_xor(cnt, 32, 64);
-            const float mean = cnt > 0 ? sum / (float)cnt : 0.0f;
-            float m2 = 0.0f;
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rbase + 32 * i + (r & 3) + 8 * (r >> 2);
-                    const float d = acc[i][j][r] - mean;
-                    if (row < g.M) m2 += d * d;
-                }
-            m2 += __shfl_xor(m2, 32, 64);
-            if (half == 0 && cok && m0 + wm * WT < g.M) {
-                g.partial[(chunk * 2 + 0) * g.N + col] = mean;
-                g.partial[(chunk * 2 + 1) * g.N + col] = m2;
-            }
-        }
-        if (EPI == EPI_STORE && g.partial) {
-            // BatchNorm-backward sums of the layer whose dZ this tile is: s1 = sum mask*dz, s2 = sum mask*dz*xhat
-            const int cc = cok ? col : 0;
-            const float mean = g.ecoef[ST_MEAN * g.N + cc], sc = g.ecoef[ST_SCALE * g.N + cc];
-            const float bt = g.ecoef[ST_BETA * g.N + cc], invstd = g.ecoef[ST_INVSTD * g.N + cc];
-            float s1 = 0.0f, s2 = 0.0f;
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rbase + 32 * i + (r & 3) + 8 * (r >> 2);
-                    const int rr = row < g.M ? row : g.M - 1;
-                    const float yy = g.ey[(long long)rr * g.ldey + cc];
-                    const float t = __builtin_fmaf(yy - mean, sc, bt);
-                    const float dzh = (row < g.M && (!g.erelu || t > 0.0f)) ? acc[i][j][r] : 0.0f;
-                    s1 += dzh;
-                    s2 += dzh * ((yy - mean) * invstd);
-                }
-            s1 += __shfl_xor(s1, 32, 64);
-            s2 += __shfl_xor(s2, 32, 64);
-            if (half == 0 && cok && m0 + wm * WT < g.M) {
-                g.partial[(chunk * 2 + 0) * g.N + col] = s1;
-                g.partial[(chunk * 2 + 1) * g.N + col] = s2;
-            }
-        }
-    }
+    gemm_epilogue<EPI, NI>(g, acc, m0 + wm * WT, n0 + wn * WT, WT, lane, (int)blockIdx.z);
 }
 
 // ------------------------------------------------------------------------------------------- BatchNorm: forward
