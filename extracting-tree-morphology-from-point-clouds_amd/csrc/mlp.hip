@@ -187,8 +187,9 @@ struct GemmArgs {
 // for problems too small to fill the chip with 128-tiles.
 // Epilogue shared by the GEMM kernels: the wave owns NI x NI 32x32 accumulators whose top-left element is
 // (row0, col0); chunk_rows = rows covered by one wave (= one statistics chunk).
-template <int EPI, int NI>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[NI][NI], int row0, int col0, int chunk_rows,
+// FULL: the wave's sub-tile lies inside the matrix -- no per-element bounds checks (64 predicated stores otherwise)
+template <int EPI, int NI, bool FULL>
+__device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& g, f32x16 (&acc)[NI][NI], int row0, int col0, int chunk_rows,
                                               int lane, int split) {
     const int l31 = lane & 31, half = lane >> 5;
     const int m0 = row0, wm = 0, WT = chunk_rows, n0 = col0, wn = 0;   // names used by the body below
@@ -200,7 +201,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[N
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
         const int col = n0 + wn * WT + 32 * j + l31;
-        const bool cok = col < g.N;
+        const bool cok = FULL || col < g.N;
         const float bias = (EPI == EPI_FWD && g.bias && cok) ? g.bias[col] : 0.0f;
         float sum = 0.0f;
         int cnt = 0;
@@ -211,7 +212,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[N
                 const int row = rbase + 32 * i + (r & 3) + 8 * (r >> 2);
                 const float val = acc[i][j][r] + bias;
                 acc[i][j][r] = val;
-                if (row < g.M) {
+                if (FULL || row < g.M) {
                     if (cok) C[(long long)row * g.ldc + col] = val;
                     sum += val;
                     ++cnt;
@@ -230,7 +231,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[N
                 for (int r = 0; r < 16; ++r) {
                     const int row = rbase + 32 * i + (r & 3) + 8 * (r >> 2);
                     const float d = acc[i][j][r] - mean;
-                    if (row < g.M) m2 += d * d;
+                    if (FULL || row < g.M) m2 += d * d;
                 }
             m2 += __shfl_xor(m2, 32, 64);
             if (half == 0 && cok && m0 + wm * WT < g.M) {
@@ -249,10 +250,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[N
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = rbase + 32 * i + (r & 3) + 8 * (r >> 2);
-                    const int rr = row < g.M ? row : g.M - 1;
+                    const int rr = (FULL || row < g.M) ? row : g.M - 1;
                     const float yy = g.ey[(long long)rr * g.ldey + cc];
                     const float t = __builtin_fmaf(yy - mean, sc, bt);
-                    const float dzh = (row < g.M && (!g.erelu || t > 0.0f)) ? acc[i][j][r] : 0.0f;
+                    const float dzh = ((FULL || row < g.M) && (!g.erelu || t > 0.0f)) ? acc[i][j][r] : 0.0f;
                     s1 += dzh;
                     s2 += dzh * ((yy - mean) * invstd);
                 }
@@ -264,6 +265,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[N
             }
         }
     }
+}
+
+template <int EPI, int NI>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[NI][NI], int row0, int col0, int chunk_rows,
+                                              int lane, int split) {
+    if (row0 + 32 * NI <= g.M && col0 + 32 * NI <= g.N)
+        gemm_epilogue_impl<EPI, NI, true>(g, acc, row0, col0, chunk_rows, lane, split);
+    else
+        gemm_epilogue_impl<EPI, NI, false>(g, acc, row0, col0, chunk_rows, lane, split);
 }
 
 // TEAMS = 4 (64-tiles only): the block holds four 256-thread teams that each contract a quarter of K into their own
