@@ -94,6 +94,8 @@ def main():
     rank, local, world = parallel.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if os.environ.get("PN2_DIST_BACKEND") == "gloo":      # rehearsal of the N > 1 path on a one-GPU box
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

@@ -259,6 +259,7 @@ __device__ __forceinline__ unsigned xcc_id() {
     return v & 7u;
 }
 
+template <bool PERWAVE>
 __global__ __launch_bounds__(kXT) void fps_xcd_kernel(const float* __restrict__ xyz, int64_t sb, int64_t sn, int64_t sc,
                                                       int B, int N, int npoint, const int64_t* __restrict__ start,
                                                       int32_t* __restrict__ out_idx, float* __restrict__ out_xyz,
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(kXT) void fps_xcd_kernel(const float* __restrict__ 
             cy = c[sc];
             cz = c[2 * sc];
         }
-        u64* gb = gran + (size_t)b * npoint * 4 * G;
+        u64* gb = gran + (size_t)b * npoint * 4 * G * (PERWAVE ? NW : 1);
 
 #ifdef PN2_FPS_DIAG
         unsigned long long st[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
@@ -396,6 +397,86 @@ __global__ __launch_bounds__(kXT) void fps_xcd_kernel(const float* __restrict__ 
             const u64 mykey =
                 bestd < 0.0f ? 0ull : (((u64)__float_as_uint(bestd)) << 32) | (u64)(0xFFFFFFFFu - (unsigned)bestn);
             const u64 wkey = pn2::wave_max_key((unsigned)(mykey >> 32), (unsigned)mykey);
+            u64 k = 0;
+            float nx = 0.f, ny = 0.f, nz = 0.f;
+            if (PERWAVE) {
+            const int buf = i & 1;
+            // Every WAVE publishes its own candidate (no workgroup-level reduction, no barrier before the exchange):
+            // entry e = g * NW + wave of the step's [4][E] granule block, E = G * NW.  One wave per workgroup polls
+            // all E entries (E / 64 per lane, every load of a poll in flight together), reduces them and hands the
+            // winner to the other waves through LDS.
+            const int E = G * NW;
+            u64* slot = gb + (size_t)i * 4 * E;
+            const unsigned tag = (unsigned)(i + 1);
+            const u64 owners = __ballot(mykey == wkey);
+            if (lane == (int)__builtin_ctzll(owners)) {
+                const int e = g * NW + wave;
+                const u64 gx = (((u64)tag) << 32) | (u64)__float_as_uint(s_px[bestj * T + tid]);
+                const u64 gy = (((u64)tag) << 32) | (u64)__float_as_uint(s_py[bestj * T + tid]);
+                const u64 gz = (((u64)tag) << 32) | (u64)__float_as_uint(s_pz[bestj * T + tid]);
+                if (local) {  // plain stores: they stay in this XCD's L2, where the group's sc1 loads find them
+                    __hip_atomic_store(slot + e, wkey | kValid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_store(slot + E + e, gx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_store(slot + 2 * E + e, gy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_store(slot + 3 * E + e, gz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                } else {
+                    st_granule(slot + e, wkey | kValid);
+                    st_granule(slot + E + e, gx);
+                    st_granule(slot + 2 * E + e, gy);
+                    st_granule(slot + 3 * E + e, gz);
+                }
+            }
+            STAMP(0);
+            if (wave == 0) {
+                constexpr int kMaxT = kMaxG * NW / 64;   // entries per lane, at most
+                const int nt = (E + 63) / 64;
+                u64 bk = 0;
+                unsigned bx = 0, by = 0, bz = 0, spins = 0;
+                for (;;) {
+                    bool ok = true;
+                    bk = 0;
+#pragma unroll
+                    for (int t = 0; t < kMaxT; ++t) {
+                        if (t < nt) {  // wave-uniform
+                            const int e = lane + 64 * t;
+                            const int ec = e < E ? e : E - 1;
+                            const u64 v0 = ld_granule(slot + ec), v1 = ld_granule(slot + E + ec);
+                            const u64 v2 = ld_granule(slot + 2 * E + ec), v3 = ld_granule(slot + 3 * E + ec);
+                            ok = ok & ((v0 & kValid) != 0) & ((unsigned)(v1 >> 32) == tag) & ((unsigned)(v2 >> 32) == tag) &
+                                 ((unsigned)(v3 >> 32) == tag);
+                            const u64 key = e < E ? (v0 & ~kValid) : 0ull;
+                            if (key > bk) {
+                                bk = key;
+                                bx = (unsigned)v1;
+                                by = (unsigned)v2;
+                                bz = (unsigned)v3;
+                            }
+                        }
+                    }
+                    if (__all(ok)) break;
+                    if (++spins > kSpinLimit) {
+                        if (lane == 0) atomicOr(&hdr->err, 1u);
+                        break;
+                    }
+                }
+                STAMP(3);
+                const u64 best = pn2::wave_max_key((unsigned)(bk >> 32), (unsigned)bk);
+                const u64 own = __ballot(bk == best);
+                if (lane == (int)__builtin_ctzll(own)) {
+                    s_win[buf] = best;
+                    s_wxyz[buf][0] = __uint_as_float(bx);
+                    s_wxyz[buf][1] = __uint_as_float(by);
+                    s_wxyz[buf][2] = __uint_as_float(bz);
+                }
+            }
+            STAMP(4);
+            lds_barrier();
+            STAMP(5);
+            k = s_win[buf];
+            nx = s_wxyz[buf][0];
+            ny = s_wxyz[buf][1];
+            nz = s_wxyz[buf][2];
+            } else {
             const int buf = i & 1;
             const u64 owners = __ballot(mykey == wkey);
             if (lane == (int)__builtin_ctzll(owners)) {
@@ -409,8 +490,8 @@ __global__ __launch_bounds__(kXT) void fps_xcd_kernel(const float* __restrict__ 
             STAMP(1);
             // workgroup winner: lane w reads wave w's candidate, one DPP reduction (instead of a 16-deep compare
             // chain in every thread).  With G > 1 only the publishing wave needs it.
-            u64 k = 0;
-            float nx = 0.f, ny = 0.f, nz = 0.f;
+            k = 0;
+            nx = ny = nz = 0.f;
             if (G == 1 || wave == 0) {
                 int kw = 0;
                 if (NW <= 4) {
@@ -484,6 +565,7 @@ __global__ __launch_bounds__(kXT) void fps_xcd_kernel(const float* __restrict__ 
                 ny = s_wxyz[buf][1];
                 nz = s_wxyz[buf][2];
             }
+            }
             far = (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull));
             cx = nx;
             cy = ny;
@@ -507,6 +589,8 @@ inline bool use_xcd_kernel(int N) {
     return N > kXT * kXPPT && N <= 64 * kXT * kXPPT;
 }
 inline int xcd_group_size(int N) { return pn2::ceil_div(N, kXT * kXPPT); }
+// every wave publishes its own candidate when one poll still covers all entries with one load set per lane
+inline bool xcd_perwave(int N) { return xcd_group_size(N) * (kXT / 64) <= 64; }
 
 struct Config {
     int ppt, t, G, groups;
@@ -545,7 +629,8 @@ void launch(const Config& c, const float* xyz, int64_t sb, int64_t sn, int64_t s
 
 extern "C" size_t pn2_fps_workspace_bytes(int B, int N, int npoint) {
     if (B <= 0 || N <= 0 || npoint <= 0) return 0;
-    if (use_xcd_kernel(N)) return sizeof(XcdHeader) + (size_t)B * npoint * 4 * xcd_group_size(N) * sizeof(u64);
+    if (use_xcd_kernel(N))
+        return sizeof(XcdHeader) + (size_t)B * npoint * 4 * xcd_group_size(N) * (xcd_perwave(N) ? kXT / 64 : 1) * sizeof(u64);
     const Config c = pick(B, N);
     if (c.G == 0) return 0;
     // [err word padded to kHdr bytes][granules: 4 per (cloud, step, member)]
@@ -563,8 +648,12 @@ extern "C" int pn2_fps_f32(const float* xyz, int64_t sb, int64_t sn, int64_t sc,
         PN2_HIP_CHECK(hipMemsetAsync(workspace, 0, need, s));
         XcdHeader* hdr = (XcdHeader*)workspace;
         u64* gran = (u64*)((char*)workspace + sizeof(XcdHeader));
-        PN2_LAUNCH("fps", (double)B * (12.0 * N + 8.0 * npoint), 0, fps_xcd_kernel, dim3(kXGrid), dim3(kXT), s, xyz, sb, sn, sc, B, N,
-                   npoint, start, out_idx, out_xyz, gran, hdr, xcd_group_size(N));
+        if (xcd_perwave(N))
+            PN2_LAUNCH("fps", (double)B * (12.0 * N + 8.0 * npoint), 0, (fps_xcd_kernel<true>), dim3(kXGrid), dim3(kXT), s, xyz, sb,
+                       sn, sc, B, N, npoint, start, out_idx, out_xyz, gran, hdr, xcd_group_size(N));
+        else
+            PN2_LAUNCH("fps", (double)B * (12.0 * N + 8.0 * npoint), 0, (fps_xcd_kernel<false>), dim3(kXGrid), dim3(kXT), s, xyz, sb,
+                       sn, sc, B, N, npoint, start, out_idx, out_xyz, gran, hdr, xcd_group_size(N));
         PN2_LAUNCH_CHECK();
         return 0;
     }

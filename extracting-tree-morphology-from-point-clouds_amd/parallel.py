@@ -22,7 +22,8 @@ def init_from_env(backend=None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" is RCCL on ROCm
+            # "nccl" is RCCL on ROCm.  PN2_DIST_BACKEND=gloo is the rehearsal path (several ranks on one GPU box)
+            backend = os.environ.get("PN2_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
