@@ -11,6 +11,8 @@
 // Empty balls (only possible when the query is not a member of the cloud) take the row argmin, first minimum,
 // like torch.argmin (lines 113-122); short rows are padded with their first hit (lines 126-130).
 #include "pn2_common.h"
+#include <cstdio>
+#include <cstdlib>
 
 namespace {
 
@@ -82,6 +84,7 @@ __global__ __launch_bounds__(kBlock) void ball_query_kernel(const float* __restr
     const int b = (int)(w / ((long long)nqg * nseg));
 
     const Cloud c{xyz + (int64_t)b * sb, sn, sc};
+    static_assert(Q % 2 == 0, "queries are tested in pairs");
     float qx[Q], qy[Q], qz[Q], qn[Q];
     int cnt[Q], first[Q];
     int32_t* row[Q];
@@ -103,23 +106,45 @@ __global__ __launch_bounds__(kBlock) void ball_query_kernel(const float* __restr
     const int n_begin = seg * seg_len;
     const int n_end = (n_begin + seg_len) < N ? (n_begin + seg_len) : N;
     const u64 lt = pn2::lanemask_lt();
+    pn2::f2 qx2[Q / 2], qy2[Q / 2], qz2[Q / 2], qn2[Q / 2];
+#pragma unroll
+    for (int i = 0; i < Q; i += 2) {
+        qx2[i / 2] = pn2::f2{qx[i], qx[i + 1]};
+        qy2[i / 2] = pn2::f2{qy[i], qy[i + 1]};
+        qz2[i / 2] = pn2::f2{qz[i], qz[i + 1]};
+        qn2[i / 2] = pn2::f2{qn[i], qn[i + 1]};
+    }
+    // the loads of block n0 + 64 are in flight while block n0 is tested
+    float nx, ny, nz;
+    c.load(n_begin + lane < n_end ? n_begin + lane : n_begin, nx, ny, nz);
     for (int n0 = n_begin; n0 < n_end; n0 += 64) {
         const int n = n0 + lane;
         const bool ok = n < n_end;
-        float x, y, z;
-        c.load(ok ? n : n_begin, x, y, z);
+        const float x = nx, y = ny, z = nz;
+        c.load(n + 64 < n_end ? n + 64 : n_begin, nx, ny, nz);
         const float pn = pn2::norm2(x, y, z);
+        const pn2::f2 x2 = {-2.0f * x, -2.0f * x}, y2 = {-2.0f * y, -2.0f * y}, z2 = {-2.0f * z, -2.0f * z},
+                      pn2v = {pn, pn};
+        bool in[Q];
+        bool any = false;
+#pragma unroll
+        for (int i = 0; i < Q; i += 2) {
+            const pn2::f2 d = pn2::sqdist2(qx2[i / 2], qy2[i / 2], qz2[i / 2], qn2[i / 2], x2, y2, z2, pn2v);
+            in[i] = ok && !(d.x > r2);
+            in[i + 1] = ok && !(d.y > r2);
+            any |= in[i] | in[i + 1];
+        }
+        if (__ballot(any) == 0) continue;  // common case: no lane holds a hit for any of the Q queries
         bool all_full = true;
 #pragma unroll
         for (int i = 0; i < Q; ++i) {
             if (cnt[i] < Keff) {
-                const float d = pn2::sqdist(qx[i], qy[i], qz[i], qn[i], x, y, z, pn);
-                const bool in = ok && !(d > r2);
-                const u64 m = __ballot(in);
+                const bool hit = in[i];
+                const u64 m = __ballot(hit);
                 if (m) {
                     if (cnt[i] == 0) first[i] = n0 + __builtin_ctzll(m);
                     const int pos = cnt[i] + __popcll(m & lt);
-                    if (in && pos < Keff) row[i][pos] = n;
+                    if (hit && pos < Keff) row[i][pos] = n;
                     cnt[i] += __popcll(m);
                 }
                 all_full = all_full && (cnt[i] >= Keff);
@@ -175,15 +200,24 @@ struct Plan {
 };
 
 Plan plan(int B, int N, int S) {
+    // 8 queries per wavefront amortise each point load over 8 tests; the index range is cut into segments until
+    // ~8192 wavefronts exist (measured on MI355X: B=1, N=262144, S=1024 -> (8,64); B=8, N=8192 -> (8,8))
     const long long queries = (long long)B * S;
     int Q = 8;
-    while (Q > 1 && queries / Q < 4096) Q >>= 1;
+    while (Q > 2 && queries < 8 * Q) Q >>= 1;
     const long long waves = (queries + Q - 1) / Q;
     long long nseg = 8192 / (waves > 0 ? waves : 1);
     const int nblk = pn2::ceil_div(N, 64);
     if (nseg > kMaxSeg) nseg = kMaxSeg;
     if (nseg > nblk / 8) nseg = nblk / 8;  // at least 512 points per segment
     if (nseg < 1) nseg = 1;
+    if (const char* e = getenv("PN2_BQ_PLAN")) {  // "Q,nseg" -- tuning aid
+        int q = 0, g = 0;
+        if (sscanf(e, "%d,%d", &q, &g) == 2 && (q == 2 || q == 4 || q == 8) && g >= 1 && g <= kMaxSeg) {
+            Q = q;
+            nseg = g;
+        }
+    }
     int seg_len = pn2::ceil_div(pn2::ceil_div(N, nseg), 64) * 64;
     nseg = pn2::ceil_div(N, seg_len);
     return Plan{Q, (int)nseg, seg_len};
@@ -219,7 +253,6 @@ extern "C" int pn2_ball_query_f32(const float* xyz, int64_t sb, int64_t sn, int6
     if (p.Q == Q_)                                                                                                    \
         PN2_LAUNCH("ball_query", bq_bytes, 0, (ball_query_kernel<Q_>), grid, block, s, xyz, sb, sn, sc, new_xyz, qb, qn, \
                    qc, B, N, S, r2, Keff, out_idx, p.seg_len, p.nseg, part_idx, part_cnt);
-    PN2_BQ_CASE(1)
     PN2_BQ_CASE(2)
     PN2_BQ_CASE(4)
     PN2_BQ_CASE(8)

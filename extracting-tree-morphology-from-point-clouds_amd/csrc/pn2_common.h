@@ -67,6 +67,15 @@ __device__ __forceinline__ float sqdist(float sx, float sy, float sz, float sn2,
     return __fadd_rn(d, dn2);
 }
 
+// Two square distances per instruction (v_pk_mul/fma/add_f32).  The dst side is passed pre-scaled by -2: scaling by
+// a power of two commutes with every rounding of the fma chain, so fma(-2z,z', fma(-2y,y', (-2x)*x')) is bit for
+// bit -2*dot3(...) (coordinates far from the subnormal range).
+using f2 = float __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 sqdist2(f2 sx, f2 sy, f2 sz, f2 sn2, f2 dx_m2, f2 dy_m2, f2 dz_m2, f2 dn2) {
+    const f2 m = __builtin_elementwise_fma(sz, dz_m2, __builtin_elementwise_fma(sy, dy_m2, sx * dx_m2));
+    return (m + sn2) + dn2;
+}
+
 __device__ __forceinline__ unsigned long long lanemask_lt() {
     return (1ull << (threadIdx.x & 63)) - 1ull;
 }

@@ -10,25 +10,33 @@
 // three_interpolate: out = (p[i0]*w0 + p[i1]*w1) + p[i2]*w2 with separate multiplies and adds, 16-byte
 // vectorised over channels, written straight into the (optional) skip-connection concat buffer.
 #include "pn2_common.h"
+#include <cstdlib>
 
 namespace {
 
 constexpr int kBlock = 256;
 constexpr int kTile = 2048;  // sampled points staged per pass: 32 KiB of LDS
 
+// P (even) dense points per thread: one broadcast LDS read of a sampled point serves P distance tests, evaluated two
+// at a time with packed fp32 instructions.
+template <int P>
 __global__ __launch_bounds__(kBlock) void three_nn_kernel(const float* __restrict__ xyz1, int64_t ab, int64_t an, int64_t ac,
                                                           const float* __restrict__ xyz2, int64_t bb, int64_t bn, int64_t bc,
                                                           int N, int S, int32_t* __restrict__ out_idx,
                                                           float* __restrict__ out_w, float* __restrict__ out_dist) {
-    __shared__ float4 tile[kTile];
+    __shared__ float4 tile[kTile + 1];  // +1: the loop below reads one entry ahead
     const int b = blockIdx.y;
-    const int n = blockIdx.x * kBlock + threadIdx.x;
-    const bool ok = n < N;
-    const float* p = xyz1 + (int64_t)b * ab + (int64_t)(ok ? n : 0) * an;
-    const float px = p[0], py = p[ac], pz = p[2 * ac];
-    const float pn = pn2::norm2(px, py, pz);
-    float d0 = __builtin_inff(), d1 = d0, d2 = d0;
-    int i0 = 0, i1 = 0, i2 = 0;
+    float px[P], py[P], pz[P], pn[P], d0[P], d1[P], d2[P];
+    int i0[P], i1[P], i2[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+        const int n = (blockIdx.x * P + j) * kBlock + threadIdx.x;
+        const float* p = xyz1 + (int64_t)b * ab + (int64_t)(n < N ? n : 0) * an;
+        px[j] = p[0], py[j] = p[ac], pz[j] = p[2 * ac];
+        pn[j] = pn2::norm2(px[j], py[j], pz[j]);
+        d0[j] = d1[j] = d2[j] = __builtin_inff();
+        i0[j] = i1[j] = i2[j] = 0;
+    }
 
     for (int s0 = 0; s0 < S; s0 += kTile) {
         const int cnt = (S - s0) < kTile ? (S - s0) : kTile;
@@ -36,43 +44,69 @@ __global__ __launch_bounds__(kBlock) void three_nn_kernel(const float* __restric
         for (int t = threadIdx.x; t < cnt; t += kBlock) {
             const float* q = xyz2 + (int64_t)b * bb + (int64_t)(s0 + t) * bn;
             const float x = q[0], y = q[bc], z = q[2 * bc];
-            tile[t] = make_float4(x, y, z, pn2::norm2(x, y, z));
+            tile[t] = make_float4(-2.0f * x, -2.0f * y, -2.0f * z, pn2::norm2(x, y, z));  // see pn2::sqdist2
         }
         __syncthreads();
+        float4 q_next = tile[0];
         for (int t = 0; t < cnt; ++t) {
-            const float4 q = tile[t];
-            const float d = pn2::sqdist(px, py, pz, pn, q.x, q.y, q.z, q.w);
-            const bool c2 = d < d2;
-            if (__ballot(c2)) {  // wave-uniform skip of the insertion once the top-3 has settled
-                const bool c1 = d < d1, c0 = d < d0;
+            const float4 q = q_next;
+            q_next = tile[t + 1];  // software pipelining: the LDS latency overlaps the P tests below
+            float d[P];
+            bool any = false;
+            const pn2::f2 qx = {q.x, q.x}, qy = {q.y, q.y}, qz = {q.z, q.z}, qw = {q.w, q.w};
+#pragma unroll
+            for (int j = 0; j < P; j += 2) {
+                const pn2::f2 dd = pn2::sqdist2(pn2::f2{px[j], px[j + 1]}, pn2::f2{py[j], py[j + 1]},
+                                                pn2::f2{pz[j], pz[j + 1]}, pn2::f2{pn[j], pn[j + 1]}, qx, qy, qz, qw);
+                d[j] = dd.x;
+                d[j + 1] = dd.y;
+                any |= (d[j] < d2[j]) | (d[j + 1] < d2[j + 1]);
+            }
+            if (__ballot(any)) {  // wave-uniform skip of the insertion once the top-3 lists have settled
                 const int s = s0 + t;
-                d2 = c1 ? d1 : (c2 ? d : d2);
-                i2 = c1 ? i1 : (c2 ? s : i2);
-                d1 = c0 ? d0 : (c1 ? d : d1);
-                i1 = c0 ? i0 : (c1 ? s : i1);
-                d0 = c0 ? d : d0;
-                i0 = c0 ? s : i0;
+#pragma unroll
+                for (int j = 0; j < P; ++j) {
+                    // scalar copies first: selects between array elements would be lowered to selects of addresses
+                    const float D = d[j], D0 = d0[j], D1 = d1[j], D2 = d2[j];
+                    const int I0 = i0[j], I1 = i1[j], I2 = i2[j];
+                    const bool c2 = D < D2, c1 = D < D1, c0 = D < D0;
+                    const float n2 = c2 ? D : D2;
+                    const int m2 = c2 ? s : I2;
+                    const float n1 = c1 ? D : D1;
+                    const int m1 = c1 ? s : I1;
+                    d2[j] = c1 ? D1 : n2;
+                    i2[j] = c1 ? I1 : m2;
+                    d1[j] = c0 ? D0 : n1;
+                    i1[j] = c0 ? I0 : m1;
+                    d0[j] = c0 ? D : D0;
+                    i0[j] = c0 ? s : I0;
+                }
             }
         }
     }
-    if (!ok) return;
-    const size_t o = ((size_t)b * N + n) * 3;
-    out_idx[o] = i0;
-    out_idx[o + 1] = i1;
-    out_idx[o + 2] = i2;
-    if (out_dist) {
-        out_dist[o] = d0;
-        out_dist[o + 1] = d1;
-        out_dist[o + 2] = d2;
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+        const int n = (blockIdx.x * P + j) * kBlock + threadIdx.x;
+        const size_t o = ((size_t)b * N + n) * 3;
+        if (n < N) {
+        out_idx[o] = i0[j];
+        out_idx[o + 1] = i1[j];
+        out_idx[o + 2] = i2[j];
+        if (out_dist) {
+            out_dist[o] = d0[j];
+            out_dist[o + 1] = d1[j];
+            out_dist[o + 2] = d2[j];
+        }
+        // blocks.py:200-203: clamp(min=1e-6), reciprocal, (r0 + r1) + r2, divide
+        const float r0 = __fdiv_rn(1.0f, d0[j] < 1e-6f ? 1e-6f : d0[j]);
+        const float r1 = __fdiv_rn(1.0f, d1[j] < 1e-6f ? 1e-6f : d1[j]);
+        const float r2 = __fdiv_rn(1.0f, d2[j] < 1e-6f ? 1e-6f : d2[j]);
+        const float sum = __fadd_rn(__fadd_rn(r0, r1), r2);
+        out_w[o] = __fdiv_rn(r0, sum);
+        out_w[o + 1] = __fdiv_rn(r1, sum);
+        out_w[o + 2] = __fdiv_rn(r2, sum);
+        }
     }
-    // blocks.py:200-203: clamp(min=1e-6), reciprocal, (r0 + r1) + r2, divide
-    const float r0 = __fdiv_rn(1.0f, d0 < 1e-6f ? 1e-6f : d0);
-    const float r1 = __fdiv_rn(1.0f, d1 < 1e-6f ? 1e-6f : d1);
-    const float r2 = __fdiv_rn(1.0f, d2 < 1e-6f ? 1e-6f : d2);
-    const float sum = __fadd_rn(__fadd_rn(r0, r1), r2);
-    out_w[o] = __fdiv_rn(r0, sum);
-    out_w[o + 1] = __fdiv_rn(r1, sum);
-    out_w[o + 2] = __fdiv_rn(r2, sum);
 }
 
 template <int V>
@@ -294,8 +328,19 @@ extern "C" int pn2_three_nn_f32(const float* xyz1, int64_t ab, int64_t an, int64
                                 int64_t bn, int64_t bc, int B, int N, int S, int32_t* out_idx, float* out_w,
                                 float* out_dist, void* stream) {
     if (!xyz1 || !xyz2 || !out_idx || !out_w || B <= 0 || N <= 0 || S < 3 || B > 65535) return PN2_E_BADARG;
-    PN2_LAUNCH("three_nn", (double)B * (12.0 * N + 12.0 * S + 36.0 * N), 0, three_nn_kernel, dim3(pn2::ceil_div(N, kBlock), B),
-               dim3(kBlock), (hipStream_t)stream, xyz1, ab, an, ac, xyz2, bb, bn, bc, N, S, out_idx, out_w, out_dist);
+    // points per thread: as many as still leave every SIMD at least one wavefront
+    int P = 2;
+    if (const char* e = getenv("PN2_TNN_P")) P = atoi(e);
+    else if ((long long)B * N >= 524288) P = 4;
+    const double tnn_bytes = (double)B * (12.0 * N + 12.0 * S + 36.0 * N);
+#define PN2_TNN_CASE(P_)                                                                                              \
+    if (P == P_)                                                                                                      \
+        PN2_LAUNCH("three_nn", tnn_bytes, 0, (three_nn_kernel<P_>), dim3(pn2::ceil_div(N, kBlock * P_), B), dim3(kBlock), \
+                   (hipStream_t)stream, xyz1, ab, an, ac, xyz2, bb, bn, bc, N, S, out_idx, out_w, out_dist);
+    PN2_TNN_CASE(2)
+    PN2_TNN_CASE(4)
+#undef PN2_TNN_CASE
+    if (P != 2 && P != 4) return PN2_E_BADARG;
     PN2_LAUNCH_CHECK();
     return 0;
 }
