@@ -166,33 +166,56 @@ __global__ __launch_bounds__(kBlock) void ball_query_kernel(const float* __restr
     }
 }
 
-// One wavefront per query: concatenate the per-segment hit lists in segment (= index) order.
+// One wavefront per query: concatenate the per-segment hit lists in segment (= index) order.  Lane g reads the count
+// of segment g (nseg <= 64), a wavefront scan turns the counts into offsets, and every output slot finds its segment
+// by bisection of the offsets in LDS -- two dependent global loads per query instead of one per segment.
 __global__ __launch_bounds__(kBlock) void ball_query_merge_kernel(const float* __restrict__ xyz, int64_t sb, int64_t sn,
                                                                   int64_t sc, const float* __restrict__ new_xyz,
                                                                   int64_t qb, int64_t qs, int64_t qc, int B, int N,
                                                                   int S, int Keff, int32_t* __restrict__ out_idx,
                                                                   int nseg, const int32_t* __restrict__ part_idx,
                                                                   const int32_t* __restrict__ part_cnt) {
-    const int lane = threadIdx.x & 63;
-    long long w = (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    __shared__ int s_off[kBlock / 64][kMaxSeg + 1];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    long long w = (long long)blockIdx.x * (kBlock / 64) + wv;
     w = __builtin_amdgcn_readfirstlane((int)w);
     if (w >= (long long)B * S) return;
     const int b = (int)(w / S), s = (int)(w % S);
     const size_t qid = (size_t)w;
     int32_t* row = out_idx + qid * Keff;
-    int total = 0, first = 0;
-    for (int seg = 0; seg < nseg && total < Keff; ++seg) {
-        const int c = part_cnt[qid * nseg + seg];
-        const int32_t* src = part_idx + (qid * nseg + seg) * Keff;
-        if (total == 0 && c > 0) first = src[0];
-        for (int j = lane; j < c && total + j < Keff; j += 64) row[total + j] = src[j];
-        total += c;
+    const int c = lane < nseg ? part_cnt[qid * nseg + lane] : 0;
+    int incl = c;  // inclusive scan over the wavefront
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
     }
-    total = total < Keff ? total : Keff;
+    int* offs = s_off[wv];
+    offs[lane + 1] = incl;
+    if (lane == 0) offs[0] = 0;
+    __builtin_amdgcn_wave_barrier();
+    const int all = offs[nseg];
+    const int total = all < Keff ? all : Keff;
+    int first = 0;
+    for (int j = lane; j < total; j += 64) {
+        int lo = 0, hi = nseg;  // largest seg with offs[seg] <= j
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (offs[mid] <= j) lo = mid; else hi = mid;
+        }
+        row[j] = part_idx[(qid * nseg + lo) * Keff + (j - offs[lo])];
+    }
+    if (total > 0 && total < Keff) {
+        // first hit = first entry of the first non-empty segment
+        const u64 nonempty = __ballot(c > 0);
+        const int seg0 = __builtin_ctzll(nonempty);
+        first = part_idx[(qid * nseg + seg0) * Keff];
+    }
+    if (total == Keff) return;
     const float* q = new_xyz + (int64_t)b * qb + (int64_t)s * qs;
     const float qx = q[0], qy = q[qc], qz = q[2 * qc];
-    const Cloud c{xyz + (int64_t)b * sb, sn, sc};
-    finish_row(c, N, row, total, first, Keff, qx, qy, qz, pn2::norm2(qx, qy, qz));
+    const Cloud cl{xyz + (int64_t)b * sb, sn, sc};
+    finish_row(cl, N, row, total, first, Keff, qx, qy, qz, pn2::norm2(qx, qy, qz));
 }
 
 struct Plan {

@@ -17,7 +17,7 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kTile = 2048;  // sampled points staged per pass: 32 KiB of LDS
 
-// P (even) dense points per thread: one broadcast LDS read of a sampled point serves P distance tests, evaluated two
+// P (1, 2 or 4) dense points per thread: one broadcast LDS read of a sampled point serves P distance tests, evaluated two
 // at a time with packed fp32 instructions.
 template <int P>
 __global__ __launch_bounds__(kBlock) void three_nn_kernel(const float* __restrict__ xyz1, int64_t ab, int64_t an, int64_t ac,
@@ -53,14 +53,20 @@ __global__ __launch_bounds__(kBlock) void three_nn_kernel(const float* __restric
             q_next = tile[t + 1];  // software pipelining: the LDS latency overlaps the P tests below
             float d[P];
             bool any = false;
-            const pn2::f2 qx = {q.x, q.x}, qy = {q.y, q.y}, qz = {q.z, q.z}, qw = {q.w, q.w};
+            if constexpr (P == 1) {
+                const float m = __builtin_fmaf(pz[0], q.z, __builtin_fmaf(py[0], q.y, __fmul_rn(px[0], q.x)));
+                d[0] = __fadd_rn(__fadd_rn(m, pn[0]), q.w);
+                any = d[0] < d2[0];
+            } else {
+                const pn2::f2 qx = {q.x, q.x}, qy = {q.y, q.y}, qz = {q.z, q.z}, qw = {q.w, q.w};
 #pragma unroll
-            for (int j = 0; j < P; j += 2) {
-                const pn2::f2 dd = pn2::sqdist2(pn2::f2{px[j], px[j + 1]}, pn2::f2{py[j], py[j + 1]},
-                                                pn2::f2{pz[j], pz[j + 1]}, pn2::f2{pn[j], pn[j + 1]}, qx, qy, qz, qw);
-                d[j] = dd.x;
-                d[j + 1] = dd.y;
-                any |= (d[j] < d2[j]) | (d[j + 1] < d2[j + 1]);
+                for (int j = 0; j + 1 < P; j += 2) {
+                    const pn2::f2 dd = pn2::sqdist2(pn2::f2{px[j], px[j + 1]}, pn2::f2{py[j], py[j + 1]},
+                                                    pn2::f2{pz[j], pz[j + 1]}, pn2::f2{pn[j], pn[j + 1]}, qx, qy, qz, qw);
+                    d[j] = dd.x;
+                    d[j + 1] = dd.y;
+                    any |= (d[j] < d2[j]) | (d[j + 1] < d2[j + 1]);
+                }
             }
             if (__ballot(any)) {  // wave-uniform skip of the insertion once the top-3 lists have settled
                 const int s = s0 + t;
@@ -329,18 +335,20 @@ extern "C" int pn2_three_nn_f32(const float* xyz1, int64_t ab, int64_t an, int64
                                 float* out_dist, void* stream) {
     if (!xyz1 || !xyz2 || !out_idx || !out_w || B <= 0 || N <= 0 || S < 3 || B > 65535) return PN2_E_BADARG;
     // points per thread: as many as still leave every SIMD at least one wavefront
-    int P = 2;
+    // measured on MI355X at 262144 x 1024: P = 1 128 us, P = 2 152 us, P = 4 190 us -- the top-3 insertion, not the
+    // LDS read or the distance, is what the loop spends its issue slots on, and fewer, fatter wavefronts hide less
+    int P = 1;
     if (const char* e = getenv("PN2_TNN_P")) P = atoi(e);
-    else if ((long long)B * N >= 524288) P = 4;
     const double tnn_bytes = (double)B * (12.0 * N + 12.0 * S + 36.0 * N);
 #define PN2_TNN_CASE(P_)                                                                                              \
     if (P == P_)                                                                                                      \
         PN2_LAUNCH("three_nn", tnn_bytes, 0, (three_nn_kernel<P_>), dim3(pn2::ceil_div(N, kBlock * P_), B), dim3(kBlock), \
                    (hipStream_t)stream, xyz1, ab, an, ac, xyz2, bb, bn, bc, N, S, out_idx, out_w, out_dist);
+    PN2_TNN_CASE(1)
     PN2_TNN_CASE(2)
     PN2_TNN_CASE(4)
 #undef PN2_TNN_CASE
-    if (P != 2 && P != 4) return PN2_E_BADARG;
+    if (P != 1 && P != 2 && P != 4) return PN2_E_BADARG;
     PN2_LAUNCH_CHECK();
     return 0;
 }

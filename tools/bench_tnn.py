@@ -21,7 +21,7 @@ xyz = np.stack([gaussian_branch_tree(N, seed=s)[0] for s in range(B)])
 x = torch.from_numpy(xyz.transpose(0, 2, 1).copy()).cuda().permute(0, 2, 1)
 _, sparse = ops.furthest_point_sample(x, S, torch.zeros(B, dtype=torch.long, device="cuda"))
 ref = None
-for cfg in ["", "2", "4"]:
+for cfg in ["", "1", "2", "4"]:
     if cfg:
         os.environ["PN2_TNN_P"] = cfg
     else:
