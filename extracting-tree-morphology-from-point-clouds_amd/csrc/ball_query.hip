@@ -271,10 +271,11 @@ extern "C" int pn2_ball_query_f32(const float* xyz, int64_t sb, int64_t sn, int6
     const long long waves = (long long)B * p.nseg * nqg;
     if (waves > 0x7FFFFFFFll) return PN2_E_BADARG;
     const dim3 grid((unsigned)((waves + 3) / 4)), block(kBlock);
+    // algorithmic bytes per SURVEY 8d; "flops" = 8 per (query, point) distance test of the brute-force scan
     const double bq_bytes = (double)B * (12.0 * N + 12.0 * S + 8.0 * S * Keff);
 #define PN2_BQ_CASE(Q_)                                                                                               \
     if (p.Q == Q_)                                                                                                    \
-        PN2_LAUNCH("ball_query", bq_bytes, 0, (ball_query_kernel<Q_>), grid, block, s, xyz, sb, sn, sc, new_xyz, qb, qn, \
+        PN2_LAUNCH("ball_query", bq_bytes, 8.0 * B * (double)S * N, (ball_query_kernel<Q_>), grid, block, s, xyz, sb, sn, sc, new_xyz, qb, qn, \
                    qc, B, N, S, r2, Keff, out_idx, p.seg_len, p.nseg, part_idx, part_cnt);
     PN2_BQ_CASE(2)
     PN2_BQ_CASE(4)

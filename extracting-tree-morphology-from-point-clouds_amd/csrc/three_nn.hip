@@ -342,7 +342,7 @@ extern "C" int pn2_three_nn_f32(const float* xyz1, int64_t ab, int64_t an, int64
     const double tnn_bytes = (double)B * (12.0 * N + 12.0 * S + 36.0 * N);
 #define PN2_TNN_CASE(P_)                                                                                              \
     if (P == P_)                                                                                                      \
-        PN2_LAUNCH("three_nn", tnn_bytes, 0, (three_nn_kernel<P_>), dim3(pn2::ceil_div(N, kBlock * P_), B), dim3(kBlock), \
+        PN2_LAUNCH("three_nn", tnn_bytes, 8.0 * B * (double)N * S, (three_nn_kernel<P_>), dim3(pn2::ceil_div(N, kBlock * P_), B), dim3(kBlock), \
                    (hipStream_t)stream, xyz1, ab, an, ac, xyz2, bb, bn, bc, N, S, out_idx, out_w, out_dist);
     PN2_TNN_CASE(1)
     PN2_TNN_CASE(2)
