@@ -24,9 +24,50 @@ def index_points(points, idx):
     return ops.GatherPoints.apply(points, idx)
 
 
+class StartIndexFeed:
+    """Persistent pinned host slots (+ their device twins) for the FPS start indices, so that a forward pass can be
+    captured in a HIP graph: a capture may not allocate pinned memory, and a replay must see NEW random starts.
+    While a feed is active every `_draw_start` call takes the next slot -- the draw lands in the slot's pinned buffer
+    and a host-to-device copy from that fixed address is enqueued (a memcpy node under capture).  `redraw()` before
+    each replay draws again, slot by slot, i.e. in the reference's order (sa1, sa2, ... per forward)."""
+    active = None
+
+    def __init__(self):
+        self.slots, self.cursor = [], 0
+
+    def begin_pass(self):
+        self.cursor = 0
+
+    def __enter__(self):
+        StartIndexFeed.active = self
+        self.begin_pass()
+        return self
+
+    def __exit__(self, *exc):
+        StartIndexFeed.active = None
+
+    def take(self, B, N, device):
+        if self.cursor == len(self.slots):          # first (uncaptured) pass: create the slot
+            self.slots.append((torch.empty(B, dtype=torch.long, pin_memory=True),
+                               torch.empty(B, dtype=torch.long, device=device), N))
+        host, dev, n = self.slots[self.cursor]
+        if host.numel() != B or n != N or dev.device != torch.device(device):
+            raise RuntimeError("StartIndexFeed: the captured forward changed shape")
+        self.cursor += 1
+        torch.randint(0, N, (B,), dtype=torch.long, out=host)
+        dev.copy_(host, non_blocking=True)
+        return dev
+
+    def redraw(self):
+        for host, _, n in self.slots:
+            torch.randint(0, n, (host.numel(),), dtype=torch.long, out=host)
+
+
 def _draw_start(B, N, device):
     # One draw per call from the global CPU generator, then moved to the device: same RNG stream
     # consumption as the reference (:79), so seeded runs pick the same first centroid.
+    if StartIndexFeed.active is not None:
+        return StartIndexFeed.active.take(B, N, device)
     return torch.randint(0, N, (B,), dtype=torch.long, pin_memory=True).to(device, non_blocking=True)
 
 

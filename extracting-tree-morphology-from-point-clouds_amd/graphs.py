@@ -1,0 +1,38 @@
+"""One training step as ONE HIP graph (extension; the reference has nothing like it).
+
+A step of the hot path is ~250 kernel launches, ~150 of them a few microseconds long; replaying them from a graph
+removes the host launch path and most of the gaps between dependent kernels.  Everything in the step is
+capturable: the library only enqueues kernels on the stream it is given, workspaces come from torch's graph-private
+pool, the loss is sync-free, and the FPS start indices are fed through `StartIndexFeed` (fixed pinned slots,
+redrawn before every replay in the reference's RNG order).  Shapes are frozen at capture: use it for fixed-size
+batches (monolithic trees, BASELINE configs[1]/[2]); ragged raster mini-batches stay eager.
+"""
+import torch
+
+from .PointNet2.pointnet2_utils import StartIndexFeed
+
+
+class GraphedTrainStep:
+    """step_fn() -> loss must do the whole step (zero grads, forward, backward, [all-reduce], optimizer) on static
+    input tensors; the optimizer must be capturable.  Call the object to run one step; it returns the (static) loss
+    tensor of that step."""
+
+    def __init__(self, step_fn, warmup=3):
+        self.feed = StartIndexFeed()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), self.feed:
+            for _ in range(warmup):
+                self.feed.begin_pass()
+                step_fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with self.feed:
+            with torch.cuda.graph(self.graph):
+                self.loss = step_fn()
+
+    def __call__(self):
+        self.feed.redraw()
+        self.graph.replay()
+        return self.loss

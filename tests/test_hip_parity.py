@@ -537,3 +537,58 @@ def test_get_loss_matches_compacted_form(pn2):
     assert abs(outs[0][0] - outs[1][0]) <= 1e-6 * abs(outs[1][0])
     np.testing.assert_allclose(outs[0][1].numpy(), outs[1][1].numpy(), rtol=1e-5, atol=1e-9)
     np.testing.assert_allclose(outs[0][2].numpy(), outs[1][2].numpy(), rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("B,N,S,scale,shift", [(1, 70000, 1024, 1.0, (0, 0, 0)), (2, 20000, 300, 10.0, (5, -3, 20)),
+                                                (1, 66000, 64, 1.0, (100, 100, 100)), (1, 40000, 128, 0.0, (1, 2, 3))])
+def test_three_nn_large_clouds_vs_oracle(pn2, O, B, N, S, scale, shift):
+    """Three-NN at full-resolution sizes, bit for bit: sampled points drawn FROM the cloud (zero distances),
+    far-from-origin coordinates (large rounding error of the expanded distance), a degenerate cloud of identical
+    points (every distance ties -> the three lowest indices)."""
+    from pn2_amd import ops
+    xyz1 = _cloud(B, N, 11, scale=scale, shift=shift)
+    rng = np.random.default_rng(5)
+    xyz2 = np.stack([xyz1[b][rng.choice(N, S, replace=False)] for b in range(B)])
+    dist, idx = O.three_nn(xyz1, xyz2)
+    gi, gw, gd = ops.three_nn(dev(xyz1), dev(xyz2), want_dist=True)
+    assert np.array_equal(bits(gd), dist.view(np.uint32))
+    assert np.array_equal(gi.cpu().numpy(), idx)
+    assert np.array_equal(bits(gw), O.three_weights(dist).view(np.uint32))
+
+
+def test_graphed_step_matches_eager(pn2):
+    """graphs.GraphedTrainStep: forward + backward captured in one HIP graph replays with fresh FPS start indices drawn
+    in the reference's RNG order -- the third pass after seeding equals the third eager pass bit for bit (forward) and
+    to atomics' rounding (gradients)."""
+    from pn2_amd.graphs import GraphedTrainStep
+    from pn2_amd.PointNet2.PointNet2 import PointNet2
+    from pn2_amd.synthetic import gaussian_branch_tree
+    n = 20000
+    xyz, off, _ = gaussian_branch_tree(n, seed=7)
+    batch = {"coords": torch.from_numpy(xyz.T.copy()[None]).cuda(), "feats": torch.ones(1, 4, n).cuda(),
+             "masks_pad": torch.ones(1, n, dtype=torch.bool).cuda(), "masks_off": torch.ones(n, dtype=torch.bool).cuda(),
+             "semantic_labels": torch.zeros(n, dtype=torch.long).cuda(), "offset_labels": torch.from_numpy(off).cuda()}
+    torch.manual_seed(21)
+    model = PointNet2(depth=4, loss_multiplier_semantic=0).cuda().train()
+    state = {k: v.clone() for k, v in model.state_dict().items()}
+
+    def step():
+        for p in model.parameters():
+            if p.grad is not None:
+                p.grad.zero_()
+        loss, _ = model(batch, return_loss=True)
+        loss.backward()
+        return loss
+
+    torch.manual_seed(22)
+    for _ in range(3):
+        eager = float(step())
+    eager_grads = [p.grad.clone() for p in model.parameters()]
+    model.load_state_dict(state)                                   # BatchNorm running statistics back to the start
+    torch.manual_seed(22)
+    graphed = GraphedTrainStep(step, warmup=1)                     # pass 1 = warm-up, pass 2 = capture (draws, no run)
+    loss = graphed()                                               # pass 3
+    torch.cuda.synchronize()
+    assert float(loss) == eager
+    for a, b in zip(eager_grads, [p.grad for p in model.parameters()]):
+        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=1e-3, atol=2e-4 * float(a.abs().max()) + 1e-12)
