@@ -23,6 +23,7 @@
 #include <stdlib.h>
 
 #include "pn2_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -998,7 +999,11 @@ struct WgradPlan {
 // dW = dY^T X reduces over `rows`; the reduction is cut into nsplit row ranges (one slab each, summed in fixed order)
 WgradPlan plan_wgrad(int rows, int cout, int cin) {
     const int tiles = pn2::ceil_div(cout, 128) * pn2::ceil_div(cin, 128);
-    int nsplit = 256 / tiles;
+    // one slab per workgroup; long reductions get two workgroups per CU (measured at 262144 rows, 128x128: 136 us with
+    // 256 workgroups = one wavefront per SIMD, 111 us with 512, +3.6 us of slab reduction)
+    int target = rows >= 65536 ? 512 : 256;
+    if (const char* e = getenv("PN2_WGRAD_BLOCKS")) target = atoi(e) > 0 ? atoi(e) : target;  // tuning aid
+    int nsplit = target / tiles;
     if (nsplit < 1) nsplit = 1;
     const int kps = pn2::ceil_div(pn2::ceil_div(rows, nsplit), BK) * BK;
     nsplit = pn2::ceil_div(rows, kps);
