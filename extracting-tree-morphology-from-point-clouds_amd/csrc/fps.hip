@@ -259,25 +259,9 @@ __device__ __forceinline__ unsigned xcc_id() {
     return v & 7u;
 }
 
-template <bool PERWAVE>
-__global__ __launch_bounds__(kXT) void fps_xcd_kernel(const float* __restrict__ xyz, int64_t sb, int64_t sn, int64_t sc,
-                                                      int B, int N, int npoint, const int64_t* __restrict__ start,
-                                                      int32_t* __restrict__ out_idx, float* __restrict__ out_xyz,
-                                                      u64* gran, XcdHeader* hdr, int G) {
-    constexpr int T = kXT, NW = T / 64;
-    __shared__ u64 s_key[2][NW];
-    __shared__ float s_xyz[2][NW][3];
-    __shared__ u64 s_win[2];
-    __shared__ float s_wxyz[2][3];
-    __shared__ int s_role[4];  // {group id or -1, rank in group, number of groups, local?}
-    // the workgroup's points once more in LDS: the lane that wins a step fetches its coordinates from here instead
-    // of every thread dragging (x, y, z) of its running best through the update loop
-    __shared__ float s_px[kXPPT * kXT], s_py[kXPPT * kXT], s_pz[kXPPT * kXT];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-
-    // ---- phase 0: where did this workgroup land?  (one lane; everything below is wave-uniform)
-    if (tid == 0) {
+// Phase 0 of the XCD-local kernels, run by one lane: which XCD did this workgroup land on, which group of G same-XCD
+// workgroups (or, failing that, of consecutive block ids) does it belong to.  s_role = {group or -1, rank, #groups, local}.
+__device__ void xcd_roles(XcdHeader* hdr, int G, int* s_role) {
         const unsigned x = xcc_id();
         const unsigned rank = atomicAdd(&hdr->cnt[x], 1u);
         __threadfence();
@@ -319,6 +303,26 @@ __global__ __launch_bounds__(kXT) void fps_xcd_kernel(const float* __restrict__ 
         s_role[2] = ngroups;
         s_role[3] = local;
     }
+
+template <bool PERWAVE>
+__global__ __launch_bounds__(kXT) void fps_xcd_kernel(const float* __restrict__ xyz, int64_t sb, int64_t sn, int64_t sc,
+                                                      int B, int N, int npoint, const int64_t* __restrict__ start,
+                                                      int32_t* __restrict__ out_idx, float* __restrict__ out_xyz,
+                                                      u64* gran, XcdHeader* hdr, int G) {
+    constexpr int T = kXT, NW = T / 64;
+    __shared__ u64 s_key[2][NW];
+    __shared__ float s_xyz[2][NW][3];
+    __shared__ u64 s_win[2];
+    __shared__ float s_wxyz[2][3];
+    __shared__ int s_role[4];  // {group id or -1, rank in group, number of groups, local?}
+    // the workgroup's points once more in LDS: the lane that wins a step fetches its coordinates from here instead
+    // of every thread dragging (x, y, z) of its running best through the update loop
+    __shared__ float s_px[kXPPT * kXT], s_py[kXPPT * kXT], s_pz[kXPPT * kXT];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // ---- phase 0: where did this workgroup land?  (one lane; everything below is wave-uniform)
+    if (tid == 0) xcd_roles(hdr, G, s_role);
     __syncthreads();
     const int group = s_role[0], g = s_role[1], ngroups = s_role[2];
     const bool local = s_role[3] != 0;
@@ -584,11 +588,296 @@ __global__ __launch_bounds__(kXT) void fps_xcd_kernel(const float* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Multi-pick rounds (same placement scheme as fps_xcd_kernel, one exchange per ROUND instead of per sample).
+//
+// After the update for centroid c the next sample is the point with the largest key.  Suppose the exchange delivers
+// the largest keys t1 > t2 > ... > tK (with coordinates).  t1 is the next sample.  If t1's update leaves t2's
+// distance unchanged (|t2 - t1|^2 >= d[t2], the very comparison the update makes), then t2 still holds the largest key
+// after that update -- every other key was below it and keys only shrink -- so t2 is the sample after t1, without
+// another exchange; likewise t3 if neither t1 nor t2 touches it, and so on until the first candidate that is touched.
+// The accepted prefix is exactly the sequential algorithm's next samples, in order; the following round applies
+// all of them in one update.  Far-apart maxima are the rule (they sit in different unsampled regions): on the
+// 262144-point tree 1024 samples take ~350 rounds with K = 4 instead of 1023 steps.
+//
+// Extracting a true top-K at every level (lane, wavefront, workgroup, group) costs K dependent reductions each, so the
+// lists are kept cheap and CERTIFIED instead: a wavefront contributes only its best point plus the key of its
+// runner-up as a bound on everything it did not list; a workgroup publishes the best of its wavefront winners plus one
+// bound (the largest key it knows of that it did not publish); the group takes the best kMK of the members'
+// candidates and H = the largest other candidate or bound.  A candidate is accepted only while its key is above H:
+// then nothing unlisted can lie between it and the candidates before it, i.e. it really is the next largest key.
+// (The largest keys sit in different unsampled regions and points are dealt to workgroups by index, so they rarely
+// share a workgroup: 368 rounds instead of the ideal 352 on the 262144-point tree.)
+constexpr int kMK = 4;  // samples accepted per round, at most
+
+__device__ __forceinline__ u64 fps_key(float d, int n) {
+    return d < 0.0f ? 0ull : (((u64)__float_as_uint(d)) << 32) | (u64)(0xFFFFFFFFu - (unsigned)n);
+}
+// wavefront max of a 64-bit key and the lane that holds it; the low word is only reduced when the high words tie
+__device__ __forceinline__ u64 wave_max_key_owner(u64 k, int& owner) {
+    const unsigned hi = (unsigned)(k >> 32), lo = (unsigned)k;
+    const unsigned mh = pn2::wave_max_u32(hi);
+    u64 who = __ballot(hi == mh);
+    unsigned ml;
+    if (__popcll(who) == 1) {
+        owner = (int)__builtin_ctzll(who);
+        ml = (unsigned)__builtin_amdgcn_readlane((int)lo, owner);
+    } else {
+        ml = pn2::wave_max_u32(hi == mh ? lo : 0u);
+        who = __ballot(hi == mh && lo == ml);
+        owner = (int)__builtin_ctzll(who);
+    }
+    return ((u64)mh << 32) | ml;
+}
+__device__ __forceinline__ u64 wave_max_key_only(u64 k) {
+    int owner;
+    return wave_max_key_owner(k, owner);
+}
+
+__global__ __launch_bounds__(kXT) void fps_multi_kernel(const float* __restrict__ xyz, int64_t sb, int64_t sn, int64_t sc,
+                                                        int B, int N, int npoint, const int64_t* __restrict__ start,
+                                                        int32_t* __restrict__ out_idx, float* __restrict__ out_xyz,
+                                                        u64* gran, XcdHeader* hdr, int G) {
+    constexpr int T = kXT, NW = T / 64;
+    constexpr int kGran = 5;  // granules per member and round: {key, x, y, z} of its best point + the bound
+    __shared__ u64 s_wkey[2][NW], s_wsec[2][NW];
+    __shared__ float s_wxyz[2][NW][3];
+    __shared__ float s_cent[2][kMK][3];
+    __shared__ u64 s_ckey[2][kMK + 1];
+    __shared__ int s_m[2];
+    __shared__ int s_role[4];
+    __shared__ float s_px[kXPPT * kXT], s_py[kXPPT * kXT], s_pz[kXPPT * kXT];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) xcd_roles(hdr, G, s_role);
+    __syncthreads();
+    const int group = s_role[0], g = s_role[1], ngroups = s_role[2];
+    const bool local = s_role[3] != 0;
+    if (group < 0 || ngroups <= 0) return;
+
+    const int ppt = (N + G * T - 1) / (G * T);
+    const int base = g * (T * ppt) + tid;
+    for (int b = group; b < B; b += ngroups) {
+        const float* p = xyz + (int64_t)b * sb;
+        f2 x[kXPPT / 2], y[kXPPT / 2], z[kXPPT / 2], d[kXPPT / 2];
+#pragma unroll
+        for (int j = 0; j < kXPPT; ++j) {
+            const int n = base + j * T;
+            const bool ok = j < ppt && n < N;
+            const float* q = p + (int64_t)(ok ? n : 0) * sn;
+            const float qx = q[0], qy = q[sc], qz = q[2 * sc];
+            x[j >> 1][j & 1] = qx;
+            y[j >> 1][j & 1] = qy;
+            z[j >> 1][j & 1] = qz;
+            d[j >> 1][j & 1] = ok ? 1e10f : -1.0f;
+            s_px[j * T + tid] = qx;
+            s_py[j * T + tid] = qy;
+            s_pz[j * T + tid] = qz;
+        }
+        int m = 1;  // centroids to apply this round
+        float ccx[kMK], ccy[kMK], ccz[kMK];
+        {
+            const int far = (int)start[b];
+            const float* c = p + (int64_t)far * sn;
+            ccx[0] = c[0], ccy[0] = c[sc], ccz[0] = c[2 * sc];
+#pragma unroll
+            for (int t = 1; t < kMK; ++t) ccx[t] = ccx[0], ccy[t] = ccy[0], ccz[t] = ccz[0];
+            if (g == 0 && tid == 0) {
+                out_idx[(size_t)b * npoint] = far;
+                if (out_xyz) {
+                    float* o = out_xyz + (size_t)b * npoint * 3;
+                    o[0] = ccx[0], o[1] = ccy[0], o[2] = ccz[0];
+                }
+            }
+        }
+        int count = 1;
+        u64* gb = gran + (size_t)b * npoint * kGran * G;
+#ifdef PN2_FPS_DIAG
+        unsigned long long st[6] = {0, 0, 0, 0, 0, 0}, tprev = 0, nrounds = 0;
+        const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime(), ct0 = __builtin_amdgcn_s_memtime();
+#endif
+
+        for (int round = 0; count < npoint; ++round) {
+            const int buf = round & 1;
+#ifdef PN2_FPS_DIAG
+            tprev = __builtin_amdgcn_s_memtime();
+            ++nrounds;
+#endif
+            // ---- update with the m accepted centroids (m is uniform over the whole group)
+#pragma unroll
+            for (int t = 0; t < kMK; ++t) {
+                if (t < m) {
+                    const f2 c2x = {ccx[t], ccx[t]}, c2y = {ccy[t], ccy[t]}, c2z = {ccz[t], ccz[t]};
+#pragma unroll
+                    for (int q = 0; q < kXPPT / 2; ++q) {
+                        const f2 dx = x[q] - c2x, dy = y[q] - c2y, dz = z[q] - c2z;
+                        const f2 dist = (dx * dx + dy * dy) + dz * dz;
+                        d[q][0] = fminf(d[q][0], dist[0]);   // slots beyond N hold -1 and stay -1
+                        d[q][1] = fminf(d[q][1], dist[1]);
+                    }
+                }
+            }
+            STAMP(0);  // update
+            // ---- this lane's best two (strict '>': the lower slot = lower index wins ties)
+            float b1d = -1.0f, b2d = -1.0f;
+            int b1j = 0, b2j = 0;
+#pragma unroll
+            for (int j = 0; j < kXPPT; ++j) {
+                const float v = d[j >> 1][j & 1];
+                const bool g1 = v > b1d, g2 = v > b2d;
+                b2d = g1 ? b1d : (g2 ? v : b2d);
+                b2j = g1 ? b1j : (g2 ? j : b2j);
+                b1d = g1 ? v : b1d;
+                b1j = g1 ? j : b1j;
+            }
+            const u64 k1 = fps_key(b1d, base + b1j * T), k2 = fps_key(b2d, base + b2j * T);
+            // ---- wavefront: best point (key + coordinates) and the runner-up's key as the bound on the rest
+            int owner;
+            const u64 w1 = wave_max_key_owner(k1, owner);
+            const u64 w2 = wave_max_key_only(lane == owner ? k2 : k1);
+            if (lane == owner) {
+                s_wkey[buf][wave] = w1;
+                s_wsec[buf][wave] = w2;
+                s_wxyz[buf][wave][0] = s_px[b1j * T + tid];
+                s_wxyz[buf][wave][1] = s_py[b1j * T + tid];
+                s_wxyz[buf][wave][2] = s_pz[b1j * T + tid];
+            }
+            STAMP(1);  // lane best two + wavefront best/bound
+            lds_barrier();
+            STAMP(2);  // barrier 1
+            if (wave == 0) {
+                // ---- workgroup: its best point + the bound on everything else it holds (the other winners and every
+                // wavefront's runner-up); the lane that holds the best winner publishes all five granules
+                u64* slot = gb + (size_t)round * kGran * G;
+                const unsigned tag = (unsigned)(round + 1);
+                const u64 mine = lane < NW ? s_wkey[buf][lane] : 0ull;
+                const u64 msec = lane < NW ? s_wsec[buf][lane] : 0ull;
+                int o1;
+                const u64 best = wave_max_key_owner(mine, o1);
+                const u64 others = lane == o1 ? msec : (mine > msec ? mine : msec);
+                const u64 bound = wave_max_key_only(others);
+                if (lane == o1) {
+                    u64* dst = slot + g;
+                    const u64 v0 = best | kValid;
+                    const u64 v1 = (((u64)tag) << 32) | (u64)__float_as_uint(s_wxyz[buf][lane < NW ? lane : 0][0]);
+                    const u64 v2 = (((u64)tag) << 32) | (u64)__float_as_uint(s_wxyz[buf][lane < NW ? lane : 0][1]);
+                    const u64 v3 = (((u64)tag) << 32) | (u64)__float_as_uint(s_wxyz[buf][lane < NW ? lane : 0][2]);
+                    const u64 v4 = bound | kValid;
+                    if (local) {
+                        __hip_atomic_store(dst, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_store(dst + G, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_store(dst + 2 * G, v2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_store(dst + 3 * G, v3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_store(dst + 4 * G, v4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    } else {
+                        st_granule(dst, v0);
+                        st_granule(dst + G, v1);
+                        st_granule(dst + 2 * G, v2);
+                        st_granule(dst + 3 * G, v3);
+                        st_granule(dst + 4 * G, v4);
+                    }
+                }
+                STAMP(3);  // workgroup candidate + publish
+                // ---- poll: lane l < G reads member l's five granules
+                u64 ek = 0, hb = 0;
+                unsigned ex = 0, ey = 0, ez = 0;
+                {
+                    const u64* src = slot + (lane < G ? lane : 0);
+                    unsigned spins = 0;
+                    for (;;) {
+                        const u64 v0 = ld_granule(src), v1 = ld_granule(src + G), v2 = ld_granule(src + 2 * G),
+                                  v3 = ld_granule(src + 3 * G), v4 = ld_granule(src + 4 * G);
+                        const bool ok = ((v0 & kValid) != 0) & ((unsigned)(v1 >> 32) == tag) & ((unsigned)(v2 >> 32) == tag) &
+                                        ((unsigned)(v3 >> 32) == tag) & ((v4 & kValid) != 0);
+                        ek = lane < G ? (v0 & ~kValid) : 0ull;
+                        hb = lane < G ? (v4 & ~kValid) : 0ull;
+                        ex = (unsigned)v1, ey = (unsigned)v2, ez = (unsigned)v3;
+                        if (__all(ok)) break;
+                        if (++spins > kSpinLimit) {
+                            if (lane == 0) atomicOr(&hdr->err, 1u);
+                            break;
+                        }
+                    }
+                }
+                STAMP(4);  // poll
+                // ---- group: the best kMK member candidates by rank (keys through LDS), H = the largest other key
+                u64 left = ek;
+#pragma unroll
+                for (int t = 0; t < kMK; ++t) {
+                    int own;
+                    const u64 k = wave_max_key_owner(left, own);
+                    if (lane == own) {
+                        s_cent[buf][t][0] = __uint_as_float(ex);
+                        s_cent[buf][t][1] = __uint_as_float(ey);
+                        s_cent[buf][t][2] = __uint_as_float(ez);
+                        s_ckey[buf][t] = k;
+                        left = 0;
+                    }
+                }
+                // everything that is not in the list: the remaining candidates and all the members' bounds
+                const u64 hmax = wave_max_key_only(left > hb ? left : hb);
+                if (lane == 0) s_ckey[buf][kMK] = 0;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                // ---- accepted prefix: above H (certified next-largest) and untouched by the ones accepted before it
+                u64 tk[kMK];
+                float tx[kMK], ty[kMK], tz[kMK];
+#pragma unroll
+                for (int t = 0; t < kMK; ++t)
+                    tk[t] = s_ckey[buf][t], tx[t] = s_cent[buf][t][0], ty[t] = s_cent[buf][t][1], tz[t] = s_cent[buf][t][2];
+                const u64 fifth = s_ckey[buf][kMK];
+                const u64 H = fifth > hmax ? fifth : hmax;
+                int acc = 1;
+#pragma unroll
+                for (int t = 1; t < kMK; ++t) {
+                    bool keep = acc == t && tk[t] != 0 && tk[t] > H;
+                    const float dt = __uint_as_float((unsigned)(tk[t] >> 32));
+#pragma unroll
+                    for (int a = 0; a < t; ++a) {
+                        const float dx = __fsub_rn(tx[t], tx[a]), dy = __fsub_rn(ty[t], ty[a]), dz = __fsub_rn(tz[t], tz[a]);
+                        keep = keep && !(pn2::norm2(dx, dy, dz) < dt);
+                    }
+                    if (keep) acc = t + 1;
+                }
+                if (acc > npoint - count) acc = npoint - count;
+                if (g == 0 && lane < acc) {
+                    const size_t o = (size_t)b * npoint + count + lane;
+                    out_idx[o] = (int)(0xFFFFFFFFu - (unsigned)(s_ckey[buf][lane] & 0xFFFFFFFFull));
+                    if (out_xyz)
+                        out_xyz[o * 3] = s_cent[buf][lane][0], out_xyz[o * 3 + 1] = s_cent[buf][lane][1],
+                                    out_xyz[o * 3 + 2] = s_cent[buf][lane][2];
+                }
+                if (lane == 0) s_m[buf] = acc;
+            }
+            STAMP(5);  // group list + chain (wave 0) / wait (others)
+            lds_barrier();
+            m = s_m[buf];
+#pragma unroll
+            for (int t = 0; t < kMK; ++t) ccx[t] = s_cent[buf][t][0], ccy[t] = s_cent[buf][t][1], ccz[t] = s_cent[buf][t][2];
+            count += m;
+        }
+#ifdef PN2_FPS_DIAG
+        if (tid == 0 && g == 0 && b == 0) {
+            unsigned long long* dbg = (unsigned long long*)((char*)hdr + 64);   // first granule bytes (diag only)
+            for (int k = 0; k < 6; ++k) dbg[k] = st[k];
+            dbg[6] = __builtin_amdgcn_s_memtime() - ct0;
+            dbg[7] = __builtin_amdgcn_s_memrealtime() - rt0;
+            dbg[8] = (unsigned long long)local;
+            dbg[9] = nrounds;
+        }
+#endif
+        __syncthreads();
+    }
+}
+
 inline bool use_xcd_kernel(int N) {
     if (getenv("PN2_FPS_NO_XCD")) return false;
     return N > kXT * kXPPT && N <= 64 * kXT * kXPPT;
 }
 inline int xcd_group_size(int N) { return pn2::ceil_div(N, kXT * kXPPT); }
+// Multi-pick rounds pay off once a group has enough members to offer several far-apart candidates per round
+// (measured: G = 32 1.73 -> 1.35 ms, G = 8 1.64 -> 1.50 ms, G = 3 0.82 -> 0.99 ms per 1024 / 512 samples).
+inline bool use_multi_pick(int N) { return getenv("PN2_FPS_NO_MULTI") == nullptr && xcd_group_size(N) >= 8; }
 // every wave publishes its own candidate when one poll still covers all entries with one load set per lane
 inline bool xcd_perwave(int N) { return xcd_group_size(N) * (kXT / 64) <= 64; }
 
@@ -629,8 +918,10 @@ void launch(const Config& c, const float* xyz, int64_t sb, int64_t sn, int64_t s
 
 extern "C" size_t pn2_fps_workspace_bytes(int B, int N, int npoint) {
     if (B <= 0 || N <= 0 || npoint <= 0) return 0;
-    if (use_xcd_kernel(N))
+    if (use_xcd_kernel(N)) {
+        if (use_multi_pick(N)) return sizeof(XcdHeader) + (size_t)B * npoint * 5 * xcd_group_size(N) * sizeof(u64);
         return sizeof(XcdHeader) + (size_t)B * npoint * 4 * xcd_group_size(N) * (xcd_perwave(N) ? kXT / 64 : 1) * sizeof(u64);
+    }
     const Config c = pick(B, N);
     if (c.G == 0) return 0;
     // [err word padded to kHdr bytes][granules: 4 per (cloud, step, member)]
@@ -648,7 +939,10 @@ extern "C" int pn2_fps_f32(const float* xyz, int64_t sb, int64_t sn, int64_t sc,
         PN2_HIP_CHECK(hipMemsetAsync(workspace, 0, need, s));
         XcdHeader* hdr = (XcdHeader*)workspace;
         u64* gran = (u64*)((char*)workspace + sizeof(XcdHeader));
-        if (xcd_perwave(N))
+        if (use_multi_pick(N))
+            PN2_LAUNCH("fps", (double)B * (12.0 * N + 8.0 * npoint), 0, fps_multi_kernel, dim3(kXGrid), dim3(kXT), s, xyz, sb, sn,
+                       sc, B, N, npoint, start, out_idx, out_xyz, gran, hdr, xcd_group_size(N));
+        else if (xcd_perwave(N))
             PN2_LAUNCH("fps", (double)B * (12.0 * N + 8.0 * npoint), 0, (fps_xcd_kernel<true>), dim3(kXGrid), dim3(kXT), s, xyz, sb,
                        sn, sc, B, N, npoint, start, out_idx, out_xyz, gran, hdr, xcd_group_size(N));
         else

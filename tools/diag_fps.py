@@ -9,7 +9,7 @@ lib = ctypes.CDLL(os.path.join(PKG_DIR, "build_diag", "libpn2hip_diag.so"))
 lib.pn2_fps_workspace_bytes.restype = ctypes.c_size_t
 vp, i64 = ctypes.c_void_p, ctypes.c_int64
 lib.pn2_fps_f32.argtypes = [vp, i64, i64, i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, ctypes.c_size_t, vp]
-for (N, npoint, B) in [(262144, 1024, 1), (2500, 100, 10), (1024, 256, 1)]:
+for (N, npoint, B) in [(262144, 1024, 1), (65536, 1024, 8), (1024, 256, 1)]:
     xyz = np.stack([gaussian_branch_tree(N, seed=s)[0] for s in range(B)])
     x = torch.from_numpy(xyz.transpose(0, 2, 1).copy()).cuda()        # [B,3,N]
     start = torch.zeros(B, dtype=torch.long, device="cuda")
@@ -22,9 +22,10 @@ for (N, npoint, B) in [(262144, 1024, 1), (2500, 100, 10), (1024, 256, 1)]:
         assert st == 0
         torch.cuda.synchronize()
     xcd = 8192 < N <= 524288
-    d = (ws[64:64 + 72] if xcd else ws[16:16 + 64]).view(torch.int64).cpu().numpy()
+    d = (ws[64:64 + 80] if xcd else ws[16:16 + 64]).view(torch.int64).cpu().numpy()
     if xcd:
-        print("  (xcd kernel, local =", int(d[8]), ")")
+        print("  (xcd kernel, local =", int(d[8]), ", rounds =", int(d[9]), ")")
+        npoint = max(int(d[9]), 1)          # per ROUND figures for the multi-pick kernel
     tot, rt = d[6], d[7]
     print(f"N={N} npoint={npoint} B={B}: {tot / npoint:.0f} cycles/step, clock {tot / (rt / 100.0):.0f} MHz, "
           + " ".join(f"{n}={v / npoint:.0f}" for n, v in zip(["compute", "bar1", "scan+pub", "poll", "reduce", "bar2"], d[:6])))

@@ -26,7 +26,7 @@ def run():
 groups = _hip.kernel_profile(run)
 tot = sum(g["ms"] for g in groups) / K
 print(f"sum of kernel time per step: {tot:.3f} ms")
-for g in sorted(groups, key=lambda g: -g["ms"])[:40]:
+for g in sorted(groups, key=lambda g: -g["ms"])[:int(os.environ.get("PN2_KT_ROWS", "40"))]:
     us = 1e3 * g["ms"] / g["calls"]
     print(f"{g['name']:24s} x{g['calls'] / K:5.1f}  {us:9.1f} us/launch  {g['ms'] / K:7.3f} ms/step  "
           f"{g['bytes'] / us / 1e3:8.1f} GB/s  {g['flops'] / us / 1e6:7.2f} TFLOP/s   bytes={g['bytes']:.3g} flops={g['flops']:.3g}")
