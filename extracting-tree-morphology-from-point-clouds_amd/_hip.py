@@ -32,6 +32,8 @@ _lp = ctypes.POINTER(MLPLayer)
 # name -> (restype, argtypes); must list every symbol include/pn2_hip.h declares (tests/test_abi.py checks)
 SIGNATURES = {
     "pn2_version": (_int, []),
+    "pn2_knn_radius_f64": (_int, [_vp, _int, _int, ctypes.c_double, _vp, _vp, _vp, _vp]),
+    "pn2_cov_eig_f64": (_int, [_vp, _int, _vp, _int, _int, _vp, _vp, _vp]),
     "pn2_arch": (ctypes.c_char_p, []),
     "pn2_square_distance_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _int, _int, _int, _vp, _vp]),
     "pn2_fps_workspace_bytes": (_sz, [_int, _int, _int]),

@@ -101,6 +101,23 @@ int pn2_three_nn_f32(const float *xyz1, int64_t ab, int64_t an, int64_t ac, cons
                      float *out_dist, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * kNN feature helpers               replaces the neighbourhood work of Modules/Features.py:111-175
+ *   (compute_normals_ckdtree :111-133, compute_curvature_ckdtree :136-158, compute_density_ckdtree :161-173,
+ *    as driven by add_features :178-229).  float64 like the reference.
+ *   pn2_knn_radius_f64: points [N][3] contiguous; nn_idx [N][k] int32 = the k nearest points of every point,
+ *     ascending by (squared distance, index) -- the point itself first, like cKDTree.query(points, k);
+ *     nn_d2 [N][k] squared distances or NULL; radius_count [N] = number of points with d^2 <= r2 (the point
+ *     itself included, like len(tree.query_ball_point(p, r))) or NULL.  k <= 16.
+ *   pn2_cov_eig_f64: for every point the np.cov (unbiased) covariance of the offsets to its first k neighbours
+ *     (rows of nn_idx, k_stride entries apart), evals [N][3] ascending, evecs [N][3][3]: row r = unit eigenvector of
+ *     evals[r], sign fixed so that its largest component is positive.
+ */
+int pn2_knn_radius_f64(const double *points, int N, int k, double r2, int32_t *nn_idx, double *nn_d2,
+                       int32_t *radius_count, void *stream);
+int pn2_cov_eig_f64(const double *points, int N, const int32_t *nn_idx, int k_stride, int k, double *evals,
+                    double *evecs, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * three_interpolate                 replaces Modules/PointNet2/blocks.py:204
  *   points2 [B,S,D] (strided), out rows of out_stride floats; the D interpolated channels are written at
  *   column out_offset (so the skip-connection concat of blocks.py:208 needs no extra copy).

@@ -254,4 +254,87 @@ void pn2o_three_interpolate_grad(const float *dout, const int64_t *idx, const fl
             }
 }
 
+
+/* ------------------------------------------------------------------------------------------------------------
+ * kNN feature helpers, float64 -- Modules/Features.py:111-175 (compute_normals_ckdtree, compute_curvature_ckdtree,
+ * compute_density_ckdtree).  The neighbour search is scipy's cKDTree in the reference (third party, not under
+ * /root/reference; any scipy): its published contract is "the k nearest by Euclidean distance, nearest first", restated
+ * here as a brute-force scan ordered by (squared distance, index).  The per-point statistics follow the reference's
+ * lines: np.cov of the offsets (mean removed, divided by k-1), eigen-decomposition of the symmetric 3x3. */
+void pn2o_knn_radius_f64(const double *pts, int N, int k, double r2, int64_t *nn_idx, double *nn_d2, int64_t *count) {
+    for (int q = 0; q < N; ++q) {
+        double bd[64];
+        int64_t bi[64];
+        for (int j = 0; j < k; ++j) { bd[j] = INFINITY; bi[j] = 0; }
+        int64_t c = 0;
+        for (int n = 0; n < N; ++n) {
+            const double dx = pts[3 * n] - pts[3 * q], dy = pts[3 * n + 1] - pts[3 * q + 1], dz = pts[3 * n + 2] - pts[3 * q + 2];
+            const double d = (dx * dx + dy * dy) + dz * dz;
+            if (d <= r2) ++c;
+            if (d < bd[k - 1]) {
+                int j = k - 1;
+                while (j > 0 && d < bd[j - 1]) { bd[j] = bd[j - 1]; bi[j] = bi[j - 1]; --j; }
+                bd[j] = d; bi[j] = n;
+            }
+        }
+        for (int j = 0; j < k; ++j) { nn_idx[(size_t)q * k + j] = bi[j]; if (nn_d2) nn_d2[(size_t)q * k + j] = bd[j]; }
+        if (count) count[q] = c;
+    }
+}
+
+static void jacobi3(double a[3][3], double v[3][3]) {
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) v[i][j] = i == j;
+    for (int sweep = 0; sweep < 50; ++sweep) {
+        const double off = fabs(a[0][1]) + fabs(a[0][2]) + fabs(a[1][2]);
+        if (off == 0.0) break;
+        for (int p = 0; p < 2; ++p) for (int q = p + 1; q < 3; ++q) {
+            if (a[p][q] == 0.0) continue;
+            const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
+            const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+            const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+            double r[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+            r[p][p] = c; r[q][q] = c; r[p][q] = s; r[q][p] = -s;
+            double ar[3][3], rtar[3][3], vr[3][3];
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+                ar[i][j] = 0; vr[i][j] = 0;
+                for (int l = 0; l < 3; ++l) { ar[i][j] += a[i][l] * r[l][j]; vr[i][j] += v[i][l] * r[l][j]; }
+            }
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+                rtar[i][j] = 0;
+                for (int l = 0; l < 3; ++l) rtar[i][j] += r[l][i] * ar[l][j];
+            }
+            for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { a[i][j] = rtar[i][j]; v[i][j] = vr[i][j]; }
+            a[p][q] = a[q][p] = 0.0;
+        }
+    }
+}
+
+/* evals [N][3] ascending; evecs [N][3][3]: row r = unit eigenvector of evals[r], largest component positive */
+void pn2o_cov_eig_f64(const double *pts, int N, const int64_t *nn_idx, int k_stride, int k, double *evals, double *evecs) {
+    for (int q = 0; q < N; ++q) {
+        double o[64][3], m[3] = {0, 0, 0};
+        for (int j = 0; j < k; ++j) {
+            const int64_t n = nn_idx[(size_t)q * k_stride + j];
+            for (int c = 0; c < 3; ++c) { o[j][c] = pts[3 * n + c] - pts[3 * q + c]; m[c] += o[j][c]; }
+        }
+        for (int c = 0; c < 3; ++c) m[c] /= (double)k;
+        double a[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, v[3][3];
+        for (int j = 0; j < k; ++j)
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) a[r][c] += (o[j][r] - m[r]) * (o[j][c] - m[c]);
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) a[r][c] /= (double)(k - 1);
+        jacobi3(a, v);
+        int ord[3] = {0, 1, 2};
+        for (int i = 0; i < 2; ++i) for (int j = 0; j < 2 - i; ++j)
+            if (a[ord[j]][ord[j]] > a[ord[j + 1]][ord[j + 1]]) { const int t = ord[j]; ord[j] = ord[j + 1]; ord[j + 1] = t; }
+        for (int r = 0; r < 3; ++r) {
+            evals[(size_t)q * 3 + r] = a[ord[r]][ord[r]];
+            double e[3] = {v[0][ord[r]], v[1][ord[r]], v[2][ord[r]]};
+            int lead = 0;
+            for (int c = 1; c < 3; ++c) if (fabs(e[c]) > fabs(e[lead])) lead = c;
+            const double sgn = e[lead] < 0 ? -1.0 : 1.0;
+            for (int c = 0; c < 3; ++c) evecs[(size_t)q * 9 + r * 3 + c] = sgn * e[c];
+        }
+    }
+}
+
 int pn2o_version(void) { return 1; }

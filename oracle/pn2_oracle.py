@@ -159,3 +159,51 @@ def three_interpolate_grad(dout, idx, w, S):
     out = np.empty((B, S, D), np.float32)
     lib().pn2o_three_interpolate_grad(pd, pi, pw, B, N, S, D, out.ctypes.data_as(_f32p))
     return out
+
+
+# ------------------------------------------------------------------------------------------- kNN feature helpers
+_f64p = ctypes.POINTER(ctypes.c_double)
+
+
+def _d(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(_f64p)
+
+
+def knn_radius(points, k, radius=None):
+    """-> (nn_idx int64 [N,k], nn_d2 [N,k], counts int64 [N] or None): Modules/Features.py:120-124, 170-172."""
+    pts, pp = _d(np.asarray(points)[:, :3])
+    n = pts.shape[0]
+    idx = np.empty((n, k), np.int64)
+    d2 = np.empty((n, k), np.float64)
+    cnt = np.empty(n, np.int64) if radius is not None else None
+    lib().pn2o_knn_radius_f64(pp, n, k, ctypes.c_double(float(radius) ** 2 if radius is not None else -1.0),
+                              idx.ctypes.data_as(_i64p), d2.ctypes.data_as(_f64p),
+                              cnt.ctypes.data_as(_i64p) if cnt is not None else None)
+    return idx, d2, cnt
+
+
+def cov_eig(points, nn_idx, k):
+    """-> (evals [N,3] ascending, evecs [N,3,3] rows): Modules/Features.py:126-130, 151-156."""
+    pts, pp = _d(np.asarray(points)[:, :3])
+    idx, pi = _i(nn_idx)
+    n = pts.shape[0]
+    evals = np.empty((n, 3), np.float64)
+    evecs = np.empty((n, 3, 3), np.float64)
+    lib().pn2o_cov_eig_f64(pp, n, pi, idx.shape[1], k, evals.ctypes.data_as(_f64p), evecs.ctypes.data_as(_f64p))
+    return evals, evecs
+
+
+def add_features(labeled_cloud):
+    """Modules/Features.py:178-229 with every feature on; the normals' signs follow this oracle's convention."""
+    pts = np.asarray(labeled_cloud)[:, :3]
+    idx, _, cnt = knn_radius(pts, 15, 0.1)
+    _, evecs15 = cov_eig(pts, idx, 15)
+    evals10, _ = cov_eig(pts, idx, 10)
+    normals = np.stack([evecs15[:, 2, 2], evecs15[:, 1, 2], evecs15[:, 0, 2]], axis=1)
+    curvature = evals10[:, 0] / (evals10.sum(1) + 1e-6)
+    height = (pts[:, 2] - pts[:, 2].min()) / (pts[:, 2].max() - pts[:, 2].min())
+    vert = np.abs(normals @ np.array([0, 0, 1]))
+    dist = np.linalg.norm(pts[:, :2] - pts[:, :2].mean(0), axis=1)
+    return np.concatenate([labeled_cloud, normals, curvature[:, None], cnt[:, None].astype(np.float64), height[:, None],
+                           vert[:, None], dist[:, None]], axis=1)
