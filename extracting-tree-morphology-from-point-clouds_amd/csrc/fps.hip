@@ -634,6 +634,7 @@ __device__ __forceinline__ u64 wave_max_key_only(u64 k) {
     return wave_max_key_owner(k, owner);
 }
 
+template <int PPT>
 __global__ __launch_bounds__(kXT) void fps_multi_kernel(const float* __restrict__ xyz, int64_t sb, int64_t sn, int64_t sc,
                                                         int B, int N, int npoint, const int64_t* __restrict__ start,
                                                         int32_t* __restrict__ out_idx, float* __restrict__ out_xyz,
@@ -646,7 +647,7 @@ __global__ __launch_bounds__(kXT) void fps_multi_kernel(const float* __restrict_
     __shared__ u64 s_ckey[2][kMK + 1];
     __shared__ int s_m[2];
     __shared__ int s_role[4];
-    __shared__ float s_px[kXPPT * kXT], s_py[kXPPT * kXT], s_pz[kXPPT * kXT];
+    __shared__ float s_px[PPT * kXT], s_py[PPT * kXT], s_pz[PPT * kXT];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) xcd_roles(hdr, G, s_role);
@@ -659,9 +660,9 @@ __global__ __launch_bounds__(kXT) void fps_multi_kernel(const float* __restrict_
     const int base = g * (T * ppt) + tid;
     for (int b = group; b < B; b += ngroups) {
         const float* p = xyz + (int64_t)b * sb;
-        f2 x[kXPPT / 2], y[kXPPT / 2], z[kXPPT / 2], d[kXPPT / 2];
+        f2 x[PPT / 2], y[PPT / 2], z[PPT / 2], d[PPT / 2];
 #pragma unroll
-        for (int j = 0; j < kXPPT; ++j) {
+        for (int j = 0; j < PPT; ++j) {
             const int n = base + j * T;
             const bool ok = j < ppt && n < N;
             const float* q = p + (int64_t)(ok ? n : 0) * sn;
@@ -709,7 +710,7 @@ __global__ __launch_bounds__(kXT) void fps_multi_kernel(const float* __restrict_
                 if (t < m) {
                     const f2 c2x = {ccx[t], ccx[t]}, c2y = {ccy[t], ccy[t]}, c2z = {ccz[t], ccz[t]};
 #pragma unroll
-                    for (int q = 0; q < kXPPT / 2; ++q) {
+                    for (int q = 0; q < PPT / 2; ++q) {
                         const f2 dx = x[q] - c2x, dy = y[q] - c2y, dz = z[q] - c2z;
                         const f2 dist = (dx * dx + dy * dy) + dz * dz;
                         d[q][0] = fminf(d[q][0], dist[0]);   // slots beyond N hold -1 and stay -1
@@ -722,7 +723,7 @@ __global__ __launch_bounds__(kXT) void fps_multi_kernel(const float* __restrict_
             float b1d = -1.0f, b2d = -1.0f;
             int b1j = 0, b2j = 0;
 #pragma unroll
-            for (int j = 0; j < kXPPT; ++j) {
+            for (int j = 0; j < PPT; ++j) {
                 const float v = d[j >> 1][j & 1];
                 const bool g1 = v > b1d, g2 = v > b2d;
                 b2d = g1 ? b1d : (g2 ? v : b2d);
@@ -778,20 +779,33 @@ __global__ __launch_bounds__(kXT) void fps_multi_kernel(const float* __restrict_
                     }
                 }
                 STAMP(3);  // workgroup candidate + publish
-                // ---- poll: lane l < G reads member l's five granules
-                u64 ek = 0, hb = 0;
-                unsigned ex = 0, ey = 0, ez = 0;
+                // ---- poll: lane l reads the five granules of members l and l + 64 (G <= 128)
+                u64 ek[2] = {0, 0}, hb = 0;
+                unsigned ex[2] = {0, 0}, ey[2] = {0, 0}, ez[2] = {0, 0};
                 {
-                    const u64* src = slot + (lane < G ? lane : 0);
+                    const bool two = G > 64;  // wave-uniform
+                    const u64* src0 = slot + (lane < G ? lane : 0);
+                    const u64* src1 = slot + (lane + 64 < G ? lane + 64 : 0);
                     unsigned spins = 0;
                     for (;;) {
-                        const u64 v0 = ld_granule(src), v1 = ld_granule(src + G), v2 = ld_granule(src + 2 * G),
-                                  v3 = ld_granule(src + 3 * G), v4 = ld_granule(src + 4 * G);
-                        const bool ok = ((v0 & kValid) != 0) & ((unsigned)(v1 >> 32) == tag) & ((unsigned)(v2 >> 32) == tag) &
-                                        ((unsigned)(v3 >> 32) == tag) & ((v4 & kValid) != 0);
-                        ek = lane < G ? (v0 & ~kValid) : 0ull;
+                        const u64 v0 = ld_granule(src0), v1 = ld_granule(src0 + G), v2 = ld_granule(src0 + 2 * G),
+                                  v3 = ld_granule(src0 + 3 * G), v4 = ld_granule(src0 + 4 * G);
+                        bool ok = ((v0 & kValid) != 0) & ((unsigned)(v1 >> 32) == tag) & ((unsigned)(v2 >> 32) == tag) &
+                                  ((unsigned)(v3 >> 32) == tag) & ((v4 & kValid) != 0);
+                        ek[0] = lane < G ? (v0 & ~kValid) : 0ull;
                         hb = lane < G ? (v4 & ~kValid) : 0ull;
-                        ex = (unsigned)v1, ey = (unsigned)v2, ez = (unsigned)v3;
+                        ex[0] = (unsigned)v1, ey[0] = (unsigned)v2, ez[0] = (unsigned)v3;
+                        if (two) {
+                            const u64 w0 = ld_granule(src1), w1 = ld_granule(src1 + G), w2 = ld_granule(src1 + 2 * G),
+                                      w3 = ld_granule(src1 + 3 * G), w4 = ld_granule(src1 + 4 * G);
+                            ok = ok & ((w0 & kValid) != 0) & ((unsigned)(w1 >> 32) == tag) & ((unsigned)(w2 >> 32) == tag) &
+                                 ((unsigned)(w3 >> 32) == tag) & ((w4 & kValid) != 0);
+                            const bool on = lane + 64 < G;
+                            ek[1] = on ? (w0 & ~kValid) : 0ull;
+                            const u64 hb1 = on ? (w4 & ~kValid) : 0ull;
+                            hb = hb1 > hb ? hb1 : hb;
+                            ex[1] = (unsigned)w1, ey[1] = (unsigned)w2, ez[1] = (unsigned)w3;
+                        }
                         if (__all(ok)) break;
                         if (++spins > kSpinLimit) {
                             if (lane == 0) atomicOr(&hdr->err, 1u);
@@ -801,20 +815,22 @@ __global__ __launch_bounds__(kXT) void fps_multi_kernel(const float* __restrict_
                 }
                 STAMP(4);  // poll
                 // ---- group: the best kMK member candidates by rank (keys through LDS), H = the largest other key
-                u64 left = ek;
 #pragma unroll
                 for (int t = 0; t < kMK; ++t) {
+                    const bool second = ek[1] > ek[0];
+                    const u64 mine = second ? ek[1] : ek[0];
                     int own;
-                    const u64 k = wave_max_key_owner(left, own);
+                    const u64 k = wave_max_key_owner(mine, own);
                     if (lane == own) {
-                        s_cent[buf][t][0] = __uint_as_float(ex);
-                        s_cent[buf][t][1] = __uint_as_float(ey);
-                        s_cent[buf][t][2] = __uint_as_float(ez);
+                        s_cent[buf][t][0] = __uint_as_float(second ? ex[1] : ex[0]);
+                        s_cent[buf][t][1] = __uint_as_float(second ? ey[1] : ey[0]);
+                        s_cent[buf][t][2] = __uint_as_float(second ? ez[1] : ez[0]);
                         s_ckey[buf][t] = k;
-                        left = 0;
+                        if (second) ek[1] = 0; else ek[0] = 0;
                     }
                 }
                 // everything that is not in the list: the remaining candidates and all the members' bounds
+                const u64 left = ek[1] > ek[0] ? ek[1] : ek[0];
                 const u64 hmax = wave_max_key_only(left > hb ? left : hb);
                 if (lane == 0) s_ckey[buf][kMK] = 0;
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -875,9 +891,29 @@ inline bool use_xcd_kernel(int N) {
     return N > kXT * kXPPT && N <= 64 * kXT * kXPPT;
 }
 inline int xcd_group_size(int N) { return pn2::ceil_div(N, kXT * kXPPT); }
+// Points per lane of the multi-pick kernel: the fewest (4, 8 or 16) whose group still fits the 32 CUs of one XCD.
+// More members per cloud = less update / selection work per workgroup AND more far-apart candidates per round, as long
+// as the hand-off stays inside an XCD's L2 (measured, 1024 samples: 8 x 65536 points 1.54 ms at 16 points per lane /
+// 8 members, 0.96 ms at 4 / 32; one 262144-point cloud 1.37 ms at 16 / 32 but 1.55 / 1.64 ms when 64 / 128 members
+// have to cross XCDs).
+inline int multi_ppt(int N) {
+    if (const char* e = getenv("PN2_FPS_PPT")) {
+        const int v = atoi(e);
+        if (v == 4 || v == 8 || v == 16) return v;
+    }
+    const int cands[3] = {4, 8, 16};
+    for (int ppt : cands)
+        if (pn2::ceil_div(N, kXT * ppt) <= 32) return ppt;
+    return 16;
+}
+inline int multi_group_size(int N) { return pn2::ceil_div(N, kXT * multi_ppt(N)); }
 // Multi-pick rounds pay off once a group has enough members to offer several far-apart candidates per round
-// (measured: G = 32 1.73 -> 1.35 ms, G = 8 1.64 -> 1.50 ms, G = 3 0.82 -> 0.99 ms per 1024 / 512 samples).
-inline bool use_multi_pick(int N) { return getenv("PN2_FPS_NO_MULTI") == nullptr && xcd_group_size(N) >= 8; }
+// (measured at 16 points per lane: G = 32 1.73 -> 1.35 ms, G = 8 1.64 -> 1.50 ms, G = 3 0.82 -> 0.99 ms).
+// ... and once there are enough samples: the first rounds (huge radii) accept one sample each, so at npoint = 100 the
+// heavier round does not pay yet (0.20 vs 0.19 ms), at 512 it does (0.57 vs 0.82 ms).
+inline bool use_multi_pick(int N, int npoint) {
+    return getenv("PN2_FPS_NO_MULTI") == nullptr && npoint >= 200 && multi_group_size(N) >= 8 && multi_group_size(N) <= 128;
+}
 // every wave publishes its own candidate when one poll still covers all entries with one load set per lane
 inline bool xcd_perwave(int N) { return xcd_group_size(N) * (kXT / 64) <= 64; }
 
@@ -919,7 +955,7 @@ void launch(const Config& c, const float* xyz, int64_t sb, int64_t sn, int64_t s
 extern "C" size_t pn2_fps_workspace_bytes(int B, int N, int npoint) {
     if (B <= 0 || N <= 0 || npoint <= 0) return 0;
     if (use_xcd_kernel(N)) {
-        if (use_multi_pick(N)) return sizeof(XcdHeader) + (size_t)B * npoint * 5 * xcd_group_size(N) * sizeof(u64);
+        if (use_multi_pick(N, npoint)) return sizeof(XcdHeader) + (size_t)B * npoint * 5 * multi_group_size(N) * sizeof(u64);
         return sizeof(XcdHeader) + (size_t)B * npoint * 4 * xcd_group_size(N) * (xcd_perwave(N) ? kXT / 64 : 1) * sizeof(u64);
     }
     const Config c = pick(B, N);
@@ -939,9 +975,19 @@ extern "C" int pn2_fps_f32(const float* xyz, int64_t sb, int64_t sn, int64_t sc,
         PN2_HIP_CHECK(hipMemsetAsync(workspace, 0, need, s));
         XcdHeader* hdr = (XcdHeader*)workspace;
         u64* gran = (u64*)((char*)workspace + sizeof(XcdHeader));
-        if (use_multi_pick(N))
-            PN2_LAUNCH("fps", (double)B * (12.0 * N + 8.0 * npoint), 0, fps_multi_kernel, dim3(kXGrid), dim3(kXT), s, xyz, sb, sn,
-                       sc, B, N, npoint, start, out_idx, out_xyz, gran, hdr, xcd_group_size(N));
+        if (use_multi_pick(N, npoint)) {
+            const int ppt = multi_ppt(N), G = multi_group_size(N);
+            const double fb = (double)B * (12.0 * N + 8.0 * npoint);
+            if (ppt == 4)
+                PN2_LAUNCH("fps", fb, 0, (fps_multi_kernel<4>), dim3(kXGrid), dim3(kXT), s, xyz, sb, sn, sc, B, N, npoint, start,
+                           out_idx, out_xyz, gran, hdr, G);
+            else if (ppt == 8)
+                PN2_LAUNCH("fps", fb, 0, (fps_multi_kernel<8>), dim3(kXGrid), dim3(kXT), s, xyz, sb, sn, sc, B, N, npoint, start,
+                           out_idx, out_xyz, gran, hdr, G);
+            else
+                PN2_LAUNCH("fps", fb, 0, (fps_multi_kernel<16>), dim3(kXGrid), dim3(kXT), s, xyz, sb, sn, sc, B, N, npoint, start,
+                           out_idx, out_xyz, gran, hdr, G);
+        }
         else if (xcd_perwave(N))
             PN2_LAUNCH("fps", (double)B * (12.0 * N + 8.0 * npoint), 0, (fps_xcd_kernel<true>), dim3(kXGrid), dim3(kXT), s, xyz, sb,
                        sn, sc, B, N, npoint, start, out_idx, out_xyz, gran, hdr, xcd_group_size(N));

@@ -57,8 +57,8 @@ def test_bad_arguments_are_rejected_on_the_host(cdll):
     assert cdll.pn2_fps_workspace_bytes(1, 2_000_000, 4) == 0          # beyond 64 members x 16384 points
     assert cdll.pn2_fps_workspace_bytes(1, 1024, 16) == 16              # single workgroup: error word only
     # XCD-local multi-pick rounds: 5 granules {key, x, y, z, bound} per member and round, at most npoint rounds
-    assert cdll.pn2_fps_workspace_bytes(1, 262144, 1024) == 64 + 1024 * 5 * 32 * 8      # 32 members
-    assert cdll.pn2_fps_workspace_bytes(8, 65536, 1024) == 64 + 8 * 1024 * 5 * 8 * 8    # 8 clouds x 8 members
+    assert cdll.pn2_fps_workspace_bytes(1, 262144, 1024) == 64 + 1024 * 5 * 32 * 8       # 32 members x 16 points per lane
+    assert cdll.pn2_fps_workspace_bytes(8, 65536, 1024) == 64 + 8 * 1024 * 5 * 32 * 8    # 8 clouds x 32 members x 4 per lane
     null = ctypes.c_void_p(None)
     i64 = ctypes.c_int64
     # null pointers -> PN2_E_BADARG before any HIP call
