@@ -64,9 +64,25 @@ def make_batch(n_points, seed, device, trees=1):
     }
 
 
+def host_cores():
+    """CPU cores this process may actually use: the cgroup quota when there is one (a GPU box hands a job a share of
+    the host -- 16 of 256 logical CPUs on the MI355X pool; 128 oversubscribed threads ran the baseline 2.3x SLOWER
+    than 16), else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(depth, n_points, seed, trees=1):
-    """One full step of the same workload through the torch-CPU restatement of the reference path."""
+    """One full step of the same workload through the torch-CPU restatement of the reference path, on as many threads
+    as the job has cores."""
     from oracle import torch_port as P
+    torch.set_num_threads(host_cores())
     batch = {k: v.cpu() for k, v in make_batch(n_points, seed, "cpu", trees).items()}
     torch.manual_seed(0)
     model = P.PortPointNet2(depth=depth).train()

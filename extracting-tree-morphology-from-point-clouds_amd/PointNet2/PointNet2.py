@@ -186,6 +186,15 @@ class PointNet2(nn.Module):
         sem_sum, off_sum, sem_cnt, off_cnt = self._accumulators(batch["cloud_length"], device)
         total_loss, n_mb = 0.0, 0
         loss_dict = {"offset_loss": 0, "semantic_loss": 0}
+        if return_loss:
+            # The reference gathers the labels on the host per mini-batch (`labels[ids.cpu()].to(device)`, lines
+            # 279-280): a device->host sync plus a CPU advanced-indexing op each time (on a many-core host the OpenMP
+            # team that op wakes then competes with the autograd thread: 20+ ms per mini-batch measured).  Same
+            # values from one upload per tree and a device-side index_select; the running loss likewise stays on the
+            # device (float64, like the reference's Python float) and is read back once.
+            sem_all = batch["semantic_labels"].squeeze().to(device)
+            off_all = batch["offset_labels"].to(device)
+            total_dev = torch.zeros((), dtype=torch.float64, device=device)
         for mini_batch in batch["mini_batches"]:
             sem, off, ids, ids_off = self._predict_minibatch(mini_batch)
             sem_sum[ids] += sem.detach()
@@ -193,17 +202,19 @@ class PointNet2(nn.Module):
             sem_cnt[ids] += 1
             off_cnt[ids_off] += 1
             if return_loss:
-                sem_lab = batch["semantic_labels"].squeeze()[ids.cpu()].to(device)
-                off_lab = batch["offset_labels"][ids_off.cpu()].to(device)
+                sem_lab = sem_all.index_select(0, ids)
+                off_lab = off_all.index_select(0, ids_off)
                 mini_loss, mini_dict = self.get_loss_hierarchical(
                     {"semantic_prediction_logits": sem, "offset_predictions": off}, sem_lab, off_lab, n_points=None)
                 if scaler:
                     scaler.scale(mini_loss * 50).backward()
                 loss_dict["offset_loss"] += mini_dict["offset_loss"]
                 loss_dict["semantic_loss"] += mini_dict["semantic_loss"]
-                total_loss += mini_loss.item()
+                total_dev += mini_loss.detach().double()
                 n_mb += 1
             del sem, off, mini_batch
+        if return_loss:
+            total_loss = float(total_dev)
         output = {"semantic_prediction_logits": self._average(sem_sum, sem_cnt),
                   "offset_predictions": self._average(off_sum, off_cnt)}
         if not return_loss:
