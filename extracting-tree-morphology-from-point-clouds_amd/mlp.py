@@ -23,6 +23,28 @@ def _bn_momentum(bn):
     return 0.0 if bn.momentum is None else float(bn.momentum)
 
 
+# The chain's backward kernels ACCUMULATE into their dweight / dbias / dgamma / dbeta targets.  With this switch on they
+# are pointed straight at the parameters' `.grad` buffers (created zeroed on first use) and the Function returns None
+# for those inputs: no zero-filled temporaries and no AccumulateGrad `add_` per parameter and backward -- ~190 tiny
+# launches per step of the depth-4 model, per mini-batch in streaming mode.  Same values (x + 0 first, then the same
+# running sum).  Turn it off for torch.autograd.grad()-style use, which expects the gradients to be RETURNED.
+FUSED_GRAD_ACCUMULATION = True
+
+
+def _grad_target(leaf, value, need, dev):
+    """-> (tensor the kernels accumulate into or None, gradient to return to autograd or None)."""
+    if value is None or not need:
+        return None, None
+    if FUSED_GRAD_ACCUMULATION and leaf is not None and leaf.is_leaf and leaf.requires_grad:
+        if leaf.grad is None:
+            leaf.grad = torch.zeros_like(leaf, memory_format=torch.contiguous_format)
+        gr = leaf.grad
+        if gr.is_contiguous() and gr.dtype == torch.float32 and gr.device == dev and gr.numel() == value.numel():
+            return gr, None
+    z = torch.zeros_like(value)
+    return z, z
+
+
 class _ChainFn(torch.autograd.Function):
     """forward(x [R,Cin], meta, *params) -> out; params = (weight, bias, gamma, beta) per layer (None allowed)."""
 
@@ -116,14 +138,16 @@ class _ChainFn(torch.autograd.Function):
             L.eps, L.momentum = spec["eps"], spec["momentum"]
             L.y, L.stats = _hip.ptr(ys[i]), _hip.ptr(stats[i])
             need = ctx.needs_input_grad[2 + 4 * i:2 + 4 * i + 4]
-            dw = torch.zeros_like(w) if need[0] else None
-            # bias of a conv that feeds a train-mode BatchNorm: the gradient is identically zero
-            db = torch.zeros_like(b) if (b is not None and need[1]) else None
-            dg = torch.zeros_like(g) if (g is not None and need[2]) else None
-            dbe = torch.zeros_like(be) if (be is not None and need[3]) else None
-            L.dweight = _hip.ptr(dw)
-            L.dbias = None if spec["has_bn"] else _hip.ptr(db)
-            L.dgamma, L.dbeta = _hip.ptr(dg), _hip.ptr(dbe)
+            leaves = spec.get("leaves", (None, None, None, None))
+            # (a bias of a conv that feeds a train-mode BatchNorm has an identically zero gradient: its target only has
+            # to exist)
+            tw, dw = _grad_target(leaves[0], w, need[0], dev)
+            tb, db = _grad_target(leaves[1], b, need[1], dev)
+            tg, dg = _grad_target(leaves[2], g, need[2], dev)
+            tbe, dbe = _grad_target(leaves[3], be, need[3], dev)
+            L.dweight = _hip.ptr(tw)
+            L.dbias = None if spec["has_bn"] else _hip.ptr(tb)
+            L.dgamma, L.dbeta = _hip.ptr(tg), _hip.ptr(tbe)
             grads += [dw, db, dg, dbe]
             if i > 0:
                 maxc = max(maxc, cin)
@@ -160,8 +184,10 @@ def chain_rows(x, layers, pool_k=1):
             if bn.track_running_stats and bn.running_mean is not None:
                 spec["running_mean"], spec["running_var"] = bn.running_mean, bn.running_var
             params += [w, conv.bias, bn.weight, bn.bias]
+            spec["leaves"] = (conv.weight, conv.bias, bn.weight, bn.bias)
         else:
             params += [w, conv.bias, None, None]
+            spec["leaves"] = (conv.weight, conv.bias, None, None)
         specs.append(spec)
     # a chain is either all batch statistics or all running statistics (module.train()/eval() sets them together)
     meta = {"layers": specs, "pool_k": int(pool_k), "training": training}
