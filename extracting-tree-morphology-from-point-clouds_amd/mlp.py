@@ -14,12 +14,14 @@ import torch
 from . import _hip
 
 
-def _bn_momentum(bn):
-    """nn.BatchNorm bookkeeping on the host side: bump num_batches_tracked, resolve momentum=None."""
+def _bn_momentum(bn, bump):
+    """nn.BatchNorm bookkeeping on the host side: num_batches_tracked += 1 (queued in `bump`: one fused launch per chain
+    instead of one per layer), resolve momentum=None."""
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
-        if bn.momentum is None:
+        if bn.momentum is None:                       # cumulative average: the new count is needed right now
+            bn.num_batches_tracked.add_(1)
             return 1.0 / float(bn.num_batches_tracked)
+        bump.append(bn.num_batches_tracked)
     return 0.0 if bn.momentum is None else float(bn.momentum)
 
 
@@ -171,7 +173,7 @@ def chain_rows(x, layers, pool_k=1):
     layers = list(layers)
     if not layers:
         return x
-    specs, params, training = [], [], False
+    specs, params, training, bump = [], [], False, []
     for conv, bn, relu in layers:
         w = conv.weight.reshape(conv.out_channels, -1)
         spec = {"cout": conv.out_channels, "has_bn": bn is not None, "relu": bool(relu), "eps": 0.0, "momentum": 0.0,
@@ -179,7 +181,7 @@ def chain_rows(x, layers, pool_k=1):
         if bn is not None:
             use_batch = bn.training or bn.running_mean is None
             training = training or use_batch
-            spec["momentum"] = _bn_momentum(bn)
+            spec["momentum"] = _bn_momentum(bn, bump)
             spec["eps"] = float(bn.eps)
             if bn.track_running_stats and bn.running_mean is not None:
                 spec["running_mean"], spec["running_var"] = bn.running_mean, bn.running_var
@@ -191,4 +193,6 @@ def chain_rows(x, layers, pool_k=1):
         specs.append(spec)
     # a chain is either all batch statistics or all running statistics (module.train()/eval() sets them together)
     meta = {"layers": specs, "pool_k": int(pool_k), "training": training}
+    if bump:
+        torch._foreach_add_(bump, 1)
     return _ChainFn.apply(x, meta, *params)
