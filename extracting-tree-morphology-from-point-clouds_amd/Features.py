@@ -12,6 +12,8 @@ not the direction of least variance.  The sign of every entry is LAPACK's choice
 direction is normalised to a positive largest component.  `compute_normals` (the sklearn variant, :11-29) takes the
 actual smallest-variance direction ``v[-1]``.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -20,6 +22,9 @@ from . import _hip
 __all__ = ["compute_normals", "compute_height", "compute_density", "compute_verticality", "compute_distance_to_center",
            "compute_curvature", "compute_normals_ckdtree", "compute_curvature_ckdtree", "compute_density_ckdtree",
            "add_features", "neighbourhoods"]
+
+
+GRID_MIN_POINTS = 4096     # below this the brute-force scan (csrc/features.hip) is as fast as building a grid
 
 
 def _device_points(points):
@@ -37,8 +42,14 @@ def neighbourhoods(points, k=15, radius=None):
     idx = torch.empty(n, k, dtype=torch.int32, device=pts.device)
     cnt = torch.empty(n, dtype=torch.int32, device=pts.device) if radius is not None else None
     r2 = float(radius) ** 2 if radius is not None else -1.0
-    _hip.call("knn_radius", _hip.lib().pn2_knn_radius_f64, pts.data_ptr(), n, int(k), r2, idx.data_ptr(), None,
-              _hip.ptr(cnt), _hip.stream_ptr())
+    lib = _hip.lib()
+    if n >= GRID_MIN_POINTS and not os.environ.get("PN2_KNN_BRUTE"):
+        ws = torch.empty(lib.pn2_knn_grid_workspace_bytes(n), dtype=torch.uint8, device=pts.device)
+        _hip.call("knn_radius_grid", lib.pn2_knn_radius_grid_f64, pts.data_ptr(), n, int(k), r2, idx.data_ptr(), None,
+                  _hip.ptr(cnt), ws.data_ptr(), ws.numel(), _hip.stream_ptr())
+    else:
+        _hip.call("knn_radius", lib.pn2_knn_radius_f64, pts.data_ptr(), n, int(k), r2, idx.data_ptr(), None,
+                  _hip.ptr(cnt), _hip.stream_ptr())
     return idx, cnt, pts
 
 

@@ -34,6 +34,8 @@ SIGNATURES = {
     "pn2_version": (_int, []),
     "pn2_knn_radius_f64": (_int, [_vp, _int, _int, ctypes.c_double, _vp, _vp, _vp, _vp]),
     "pn2_cov_eig_f64": (_int, [_vp, _int, _vp, _int, _int, _vp, _vp, _vp]),
+    "pn2_knn_grid_workspace_bytes": (_sz, [_int]),
+    "pn2_knn_radius_grid_f64": (_int, [_vp, _int, _int, ctypes.c_double, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pn2_arch": (ctypes.c_char_p, []),
     "pn2_square_distance_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _int, _int, _int, _vp, _vp]),
     "pn2_fps_workspace_bytes": (_sz, [_int, _int, _int]),

@@ -116,6 +116,13 @@ int pn2_knn_radius_f64(const double *points, int N, int k, double r2, int32_t *n
                        int32_t *radius_count, void *stream);
 int pn2_cov_eig_f64(const double *points, int N, const int32_t *nn_idx, int k_stride, int k, double *evals,
                     double *evecs, void *stream);
+/* Same contract and bit-identical results through a hashed cell grid (csrc/knn_grid.hip): the cloud is binned into
+ * cells (adaptive edge), every query's 27 surrounding cells are searched by one wavefront and certified against the
+ * cell edge; queries the grid cannot settle are redone by a full scan.  radius_count uses a second grid whose edge is
+ * the radius (r2 < 0 or radius_count == NULL: no count).  workspace: pn2_knn_grid_workspace_bytes(N) bytes. */
+size_t pn2_knn_grid_workspace_bytes(int N);
+int pn2_knn_radius_grid_f64(const double *points, int N, int k, double r2, int32_t *nn_idx, double *nn_d2,
+                            int32_t *radius_count, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * three_interpolate                 replaces Modules/PointNet2/blocks.py:204

@@ -100,3 +100,49 @@ def test_hip_knn_ragged_sizes_vs_oracle(O):
         oi, _, oc = O.knn_radius(pts, k, 0.5)
         np.testing.assert_array_equal(idx.cpu().numpy(), oi)
         np.testing.assert_array_equal(cnt.cpu().numpy(), oc)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,n,k,r", [("tree", 60000, 15, 0.1), ("tree", 5000, 10, 0.1), ("uniform", 30000, 16, 0.05),
+                                        ("lumps", 20000, 15, 0.2), ("line", 8192, 3, 0.01), ("same", 4500, 5, 0.1)])
+def test_grid_knn_is_the_brute_force_result(kind, n, k, r):
+    """csrc/knn_grid.hip vs the full scan of csrc/features.hip, bit for bit (indices, squared distances, radius counts):
+    a tree, uniform noise, tight lumps far apart (most 27-cell searches fail their certificate -> slow path), a line
+    with duplicated points (ties), and a cloud of identical points (one cell, every query on the slow path)."""
+    load_pkg()
+    import ctypes
+    import torch
+    from pn2_amd import _hip
+    from pn2_amd.synthetic import gaussian_branch_tree
+    rng = np.random.default_rng(7)
+    if kind == "tree":
+        pts = gaussian_branch_tree(n, seed=9)[0].astype(np.float64)
+    elif kind == "uniform":
+        pts = rng.uniform(-3, 5, size=(n, 3))
+    elif kind == "lumps":
+        centres = rng.uniform(-50, 50, size=(40, 3))
+        pts = centres[rng.integers(0, 40, n)] + rng.normal(size=(n, 3)) * 0.01
+    elif kind == "line":
+        pts = np.stack([np.linspace(0, 1, n), np.zeros(n), np.zeros(n)], axis=1)
+        pts[1::2] = pts[0::2]                                          # every point twice
+    else:
+        pts = np.tile(np.array([[1.5, -2.0, 7.0]]), (n, 1))
+    p = torch.from_numpy(np.ascontiguousarray(pts)).cuda()
+    lib = _hip.lib()
+    out = {}
+    for tag in ("brute", "grid"):
+        idx = torch.empty(n, k, dtype=torch.int32, device="cuda")
+        d2 = torch.empty(n, k, dtype=torch.float64, device="cuda")
+        cnt = torch.empty(n, dtype=torch.int32, device="cuda")
+        if tag == "brute":
+            st = lib.pn2_knn_radius_f64(p.data_ptr(), n, k, r * r, idx.data_ptr(), d2.data_ptr(), cnt.data_ptr(), _hip.stream_ptr())
+        else:
+            ws = torch.empty(lib.pn2_knn_grid_workspace_bytes(n), dtype=torch.uint8, device="cuda")
+            st = lib.pn2_knn_radius_grid_f64(p.data_ptr(), n, k, r * r, idx.data_ptr(), d2.data_ptr(), cnt.data_ptr(),
+                                             ws.data_ptr(), ws.numel(), _hip.stream_ptr())
+        assert st == 0
+        torch.cuda.synchronize()
+        out[tag] = (idx.cpu().numpy(), d2.cpu().numpy(), cnt.cpu().numpy())
+    np.testing.assert_array_equal(out["grid"][1].view(np.uint64), out["brute"][1].view(np.uint64))
+    np.testing.assert_array_equal(out["grid"][0], out["brute"][0])
+    np.testing.assert_array_equal(out["grid"][2], out["brute"][2])

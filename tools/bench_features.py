@@ -28,10 +28,23 @@ t0 = time.perf_counter()
 out = F.add_features(cloud)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
-groups = _hip.kernel_profile(lambda: (F.add_features(cloud), torch.cuda.synchronize()))
-kernels = {g["name"]: {"ms": g["ms"] / g["calls"], "calls": g["calls"],
-                       "TFLOPs_fp64": g["flops"] / (g["ms"] / g["calls"] * 1e-3) / 1e12 if g["flops"] else None} for g in groups}
-knn = kernels.get("knn_radius", {})
+def kernel_ms():
+    groups = _hip.kernel_profile(lambda: (F.add_features(cloud), torch.cuda.synchronize()))
+    out = {}
+    for g in groups:
+        k = out.setdefault(g["name"], {"ms": 0.0, "calls": 0, "flops": 0.0})
+        k["ms"] += g["ms"]
+        k["calls"] += g["calls"]
+        k["flops"] += g["flops"] * g["calls"]
+    return out
+
+
+kernels = kernel_ms()
+os.environ["PN2_KNN_BRUTE"] = "1"
+brute = kernel_ms()
+del os.environ["PN2_KNN_BRUTE"]
+bf = brute.get("knn_radius", {"ms": 0.0, "flops": 0.0})
+grid_ms = sum(v["ms"] for k, v in kernels.items() if k.startswith("knn_grid"))
 from oracle.features_port import add_features_port  # noqa: E402
 t0 = time.perf_counter()
 ref = add_features_port(cloud, sample=SAMPLE)
@@ -41,10 +54,12 @@ cur_err = float(np.abs(ref[:, 10] - out[:SAMPLE, 10]).max())
 print(json.dumps({
     "metric": "points/sec, add_features (k=15 normals, k=10 curvature, r=0.1 density, height, verticality, distance)",
     "value": N / dt, "unit": "points/s", "n_points": N, "seconds": dt, "dtype": "f64", "data": "synthetic",
-    "kernels": kernels,
-    "roofline": {"kernel": "knn_radius", "bound": "valu_fp64", "achieved": knn.get("TFLOPs_fp64"), "peak": FP64_PEAK_TFLOPS,
-                 "unit": "TFLOP/s", "frac": (knn.get("TFLOPs_fp64") or 0) / FP64_PEAK_TFLOPS,
-                 "work": "8 flop x N^2 distance tests (brute force)"},
+    "kernels": {k: {"ms": v["ms"], "calls": v["calls"]} for k, v in kernels.items()},
+    "neighbour_search": {"grid_ms": grid_ms, "brute_force_ms": bf["ms"], "speedup": bf["ms"] / grid_ms if grid_ms else None,
+                         "brute_force_TFLOPs_fp64": bf["flops"] / (bf["ms"] * 1e-3) / 1e12 if bf["ms"] else None,
+                         "brute_force_frac_of_fp64_peak": bf["flops"] / (bf["ms"] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if bf["ms"] else None,
+                         "note": "grid = hashed cell grid, 3 passes (h, 3h, 9h) + full scan of the leftovers + radius grid; "
+                                 "brute force = 8 flop x N^2 distance tests in fp64"},
     "cpu_baseline": {"value": SAMPLE / dc, "unit": "points/s", "cores": 1, "kind": "port",
                      "sample": f"first {SAMPLE} points of the same cloud (tree over all {N}), {dc:.1f} s"},
     "gpu_over_cpu": (N / dt) / (SAMPLE / dc),
