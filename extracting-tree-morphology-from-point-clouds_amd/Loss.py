@@ -7,7 +7,39 @@ with independent random permutations drawn from the global CPU generator, like t
 import torch
 import torch.nn.functional as F
 
+from . import _hip
 from .Utils import cuda_cast
+
+
+class MaskedPointLoss(torch.autograd.Function):
+    """(sem [R,2], off [R,3], pad, off_mask, cum_pad, cum_off, sem_labels, off_labels) -> tensor [2] =
+    (semantic loss, offset loss) of the masked rows; one forward and one backward kernel (csrc/loss.hip)."""
+
+    @staticmethod
+    def forward(ctx, sem, off, pad, off_mask, cum_pad, cum_off, sem_labels, off_labels):
+        _hip.require_device(sem, off)
+        lib = _hip.lib()
+        sem, off = sem.contiguous(), off.contiguous()
+        sem_labels, off_labels = sem_labels.contiguous(), off_labels.contiguous().float()
+        R = sem.shape[0]
+        out = torch.empty(2, dtype=torch.float32, device=sem.device)
+        ws = torch.empty(max(lib.pn2_point_loss_workspace_bytes(R), 16), dtype=torch.uint8, device=sem.device)
+        _hip.call("point_loss_fwd", lib.pn2_point_loss_fwd_f32, sem.data_ptr(), off.data_ptr(), pad.data_ptr(),
+                  off_mask.data_ptr(), cum_pad.data_ptr(), cum_off.data_ptr(), sem_labels.data_ptr(), sem_labels.numel(),
+                  off_labels.data_ptr(), off_labels.shape[0], R, out.data_ptr(), ws.data_ptr(), ws.numel(), _hip.stream_ptr())
+        ctx.save_for_backward(sem, off, pad, off_mask, cum_pad, cum_off, sem_labels, off_labels)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        sem, off, pad, off_mask, cum_pad, cum_off, sem_labels, off_labels = ctx.saved_tensors
+        g = g.contiguous().float()
+        dsem, doff = torch.empty_like(sem), torch.empty_like(off)
+        _hip.call("point_loss_bwd", _hip.lib().pn2_point_loss_bwd_f32, sem.data_ptr(), off.data_ptr(), pad.data_ptr(),
+                  off_mask.data_ptr(), cum_pad.data_ptr(), cum_off.data_ptr(), sem_labels.data_ptr(), sem_labels.numel(),
+                  off_labels.data_ptr(), off_labels.shape[0], sem.shape[0], g.data_ptr(), dsem.data_ptr(), doff.data_ptr(),
+                  _hip.stream_ptr())
+        return dsem, doff, None, None, None, None, None, None
 
 
 @cuda_cast

@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..Loss import point_wise_loss
+from ..Loss import MaskedPointLoss, point_wise_loss
 from ..Utils import cuda_cast
 from .blocks import (MLP, ConvHead, PointNetFeaturePropagation, PointNetSetAbstraction,
                      PointNetSetAbstractionMsg)
@@ -129,19 +129,21 @@ class PointNet2(nn.Module):
             return self.get_loss_hierarchical({"semantic_prediction_logits": sem_v, "offset_predictions": off_v},
                                               semantic_labels, offset_labels)
         pad = masks_pad.reshape(-1)
-        rank = torch.cumsum(pad, 0) - 1                      # index of a real row among the real rows
-        n_valid = (rank[-1] + 1).clamp_min(1)
-        rank = rank.clamp(0, semantic_labels.numel() - 1)
-        sem_labels = semantic_labels.reshape(-1).index_select(0, rank)
-        off_mask = pad & masks_off.index_select(0, rank.clamp_max(masks_off.numel() - 1))
-        rank_off = torch.cumsum(off_mask, 0) - 1
-        n_off = (rank_off[-1] + 1).clamp_min(1)
-        off_labels = offset_labels.index_select(0, rank_off.clamp(0, offset_labels.shape[0] - 1))
-
-        ce = F.cross_entropy(sem, sem_labels, reduction="none")
-        semantic_loss = (ce * pad).sum() / n_valid
-        dist = torch.sqrt(torch.clamp((off - off_labels).pow(2).sum(1), min=1e-8))
-        offset_loss = (dist * off_mask).sum() / n_off
+        cum_pad = torch.cumsum(pad, 0)                       # cum - 1 = index of a real row among the real rows
+        off_mask = pad & masks_off.index_select(0, (cum_pad - 1).clamp(0, masks_off.numel() - 1))
+        cum_off = torch.cumsum(off_mask, 0)
+        if sem.is_cuda and semantic_labels.dtype == torch.long:
+            both = MaskedPointLoss.apply(sem, off, pad, off_mask, cum_pad, cum_off, semantic_labels.reshape(-1), offset_labels)
+            semantic_loss, offset_loss = both[0], both[1]
+        else:
+            rank = (cum_pad - 1).clamp(0, semantic_labels.numel() - 1)
+            n_valid, n_off = cum_pad[-1].clamp_min(1), cum_off[-1].clamp_min(1)
+            sem_labels = semantic_labels.reshape(-1).index_select(0, rank)
+            off_labels = offset_labels.index_select(0, (cum_off - 1).clamp(0, offset_labels.shape[0] - 1))
+            ce = F.cross_entropy(sem, sem_labels, reduction="none")
+            semantic_loss = (ce * pad).sum() / n_valid
+            dist = torch.sqrt(torch.clamp((off - off_labels).pow(2).sum(1), min=1e-8))
+            offset_loss = (dist * off_mask).sum() / n_off
         loss_dict = {"semantic_loss": semantic_loss * self.loss_multiplier_semantic,
                      "offset_loss": offset_loss * self.loss_multiplier_offset}
         return sum(loss_dict.values()), loss_dict

@@ -32,6 +32,9 @@ _lp = ctypes.POINTER(MLPLayer)
 # name -> (restype, argtypes); must list every symbol include/pn2_hip.h declares (tests/test_abi.py checks)
 SIGNATURES = {
     "pn2_version": (_int, []),
+    "pn2_point_loss_workspace_bytes": (_sz, [_int]),
+    "pn2_point_loss_fwd_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _int, _vp, _vp, _sz, _vp]),
+    "pn2_point_loss_bwd_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _int, _vp, _vp, _vp, _vp]),
     "pn2_knn_radius_f64": (_int, [_vp, _int, _int, ctypes.c_double, _vp, _vp, _vp, _vp]),
     "pn2_cov_eig_f64": (_int, [_vp, _int, _vp, _int, _int, _vp, _vp, _vp]),
     "pn2_knn_grid_workspace_bytes": (_sz, [_int]),

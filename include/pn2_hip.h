@@ -101,6 +101,24 @@ int pn2_three_nn_f32(const float *xyz1, int64_t ab, int64_t an, int64_t ac, cons
                      float *out_dist, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * masked point-wise loss            replaces the arithmetic of Modules/Loss.py:6-36 (point_wise_loss) under the masks
+ *                                   of Modules/PointNet2/PointNet2.py:180-207 (get_loss)
+ *   sem [R,2], off [R,3] predictions of the padded rows; pad / off_mask [R] (1 byte each); cum_pad / cum_off [R]
+ *   inclusive int64 prefix sums of the masks (cum - 1 = the row's position in the compacted label arrays sem_labels
+ *   [n_sem] int64, off_labels [n_off,3]).  out2 = {sum_pad CE / max(n_valid,1), sum_offmask sqrt(max(|d|^2,1e-8)) /
+ *   max(n_off_rows,1)}.  Backward: grad2 = d/d out2 -> dsem [R,2], doff [R,3] (zero on masked-out rows).
+ */
+size_t pn2_point_loss_workspace_bytes(int R);
+int pn2_point_loss_fwd_f32(const float *sem, const float *off, const unsigned char *pad, const unsigned char *off_mask,
+                           const int64_t *cum_pad, const int64_t *cum_off, const int64_t *sem_labels, int64_t n_sem,
+                           const float *off_labels, int64_t n_off, int R, float *out2, void *workspace,
+                           size_t workspace_bytes, void *stream);
+int pn2_point_loss_bwd_f32(const float *sem, const float *off, const unsigned char *pad, const unsigned char *off_mask,
+                           const int64_t *cum_pad, const int64_t *cum_off, const int64_t *sem_labels, int64_t n_sem,
+                           const float *off_labels, int64_t n_off, int R, const float *grad2, float *dsem, float *doff,
+                           void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * kNN feature helpers               replaces the neighbourhood work of Modules/Features.py:111-175
  *   (compute_normals_ckdtree :111-133, compute_curvature_ckdtree :136-158, compute_density_ckdtree :161-173,
  *    as driven by add_features :178-229).  float64 like the reference.
