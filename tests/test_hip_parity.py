@@ -156,9 +156,12 @@ def _cloud(B, N, seed, scale=1.0, shift=(0, 0, 0)):
 
 
 @pytest.mark.parametrize("B,N,npoint", [(3, 5000, 37), (1, 64, 64), (2, 1, 3), (5, 333, 400), (1, 20000, 64),
-                                         (2, 70001, 50), (300, 257, 9)])
+                                         (2, 70001, 50), (300, 257, 9),
+                                         # multi-pick rounds (>= 200 samples, >= 8 members): 4 / 8 / 16 points per lane
+                                         (3, 20000, 512), (2, 70001, 300), (1, 150000, 256), (9, 16390, 200)])
 def test_fps_vs_oracle(pn2, O, B, N, npoint):
-    """single- and multi-workgroup clouds, ragged sizes, npoint > N (repeats), more clouds than workgroups."""
+    """single- and multi-workgroup clouds, ragged sizes, npoint > N (repeats), more clouds than workgroups, and the
+    multi-pick kernel with zero-padded tails (thousands of identical points: every key tie is broken by index)."""
     from pn2_amd import ops
     xyz = _cloud(B, N, seed=N + B, scale=0.5, shift=(10.0, -20.0, 15.0))
     if N > 100:
