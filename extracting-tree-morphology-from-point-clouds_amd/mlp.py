@@ -98,6 +98,7 @@ class _ChainFn(torch.autograd.Function):
                   int(pool_k), out.data_ptr(), _hip.ptr(arg), ws.data_ptr(), ws.numel(), _hip.stream_ptr(),
                   nbytes=nbytes, flops=flops)
         ctx.meta = meta
+        ctx.arr = arr
         ctx.dims = (rows, cin0)
         ctx.save_for_backward(x, arg, *[t for t in ys if t is not None], *[t for t in stats if t is not None], *params)
         ctx.layout = ([t is not None for t in ys], [t is not None for t in stats])
@@ -126,19 +127,12 @@ class _ChainFn(torch.autograd.Function):
         params = saved[pos:]
         dev = x.device
         dout = dout.contiguous()
-        arr = (_hip.MLPLayer * n)()
+        arr = ctx.arr                                      # the forward's layer table (shapes, weights, y, stats)
         grads = []
         cin, maxc = cin0, 0
         for i, spec in enumerate(meta["layers"]):
             w, b, g, be = params[4 * i:4 * i + 4]
-            cout = spec["cout"]
             L = arr[i]
-            L.cin, L.cout = cin, cout
-            L.weight, L.bias = w.data_ptr(), _hip.ptr(b)
-            L.has_bn, L.relu = int(spec["has_bn"]), int(spec["relu"])
-            L.gamma, L.beta = _hip.ptr(g), _hip.ptr(be)
-            L.eps, L.momentum = spec["eps"], spec["momentum"]
-            L.y, L.stats = _hip.ptr(ys[i]), _hip.ptr(stats[i])
             need = ctx.needs_input_grad[2 + 4 * i:2 + 4 * i + 4]
             leaves = spec.get("leaves", (None, None, None, None))
             # (a bias of a conv that feeds a train-mode BatchNorm has an identically zero gradient: its target only has
@@ -153,7 +147,7 @@ class _ChainFn(torch.autograd.Function):
             grads += [dw, db, dg, dbe]
             if i > 0:
                 maxc = max(maxc, cin)
-            cin = cout
+            cin = spec["cout"]
         maxc = max(maxc, cin)
         dx = torch.empty(rows, cin0, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
         sa = torch.empty(rows * maxc, dtype=torch.float32, device=dev)
