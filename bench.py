@@ -87,15 +87,18 @@ def cpu_baseline(depth, n_points, seed, trees=1):
     torch.manual_seed(0)
     model = P.PortPointNet2(depth=depth).train()
     opt = torch.optim.AdamW(model.parameters(), lr=0.01, weight_decay=1e-3)
-    t0 = time.perf_counter()
-    opt.zero_grad()
-    loss, _, _, _ = P.loss_from_batch(model, batch, mult_sem=0.0)
-    (loss * 50).backward()
-    opt.step()
-    dt = time.perf_counter() - t0
+    times = []
+    for _ in range(2):                      # the second repetition runs warm; the better one is reported
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        loss, _, _, _ = P.loss_from_batch(model, batch, mult_sem=0.0)
+        (loss * 50).backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    dt = min(times)
     return {"value": trees * n_points / dt, "unit": "points/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 step (fwd+loss+bwd+AdamW) of the same depth-{depth} batch of {trees} x {n_points}-point tree(s), "
-                      f"torch CPU fp32, {dt:.2f} s, no warm-up"}
+            "sample": f"best of 2 steps (fwd+loss+bwd+AdamW) of the same depth-{depth} batch of {trees} x {n_points}-point "
+                      f"tree(s), torch CPU fp32, {times[0]:.2f} s and {times[1]:.2f} s"}
 
 
 def main():
