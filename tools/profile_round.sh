@@ -20,4 +20,8 @@ timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmc_fet
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pmc_write -o w -- python3 $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 > /dev/null 2>> $O/rocprof.err
 python3 $R/tools/pmc_traffic.py $(find /tmp/pmc_fetch -name "*counter_collection.csv" | head -1) $(find /tmp/pmc_write -name "*counter_collection.csv" | head -1) $O/pmc_traffic.json > $O/pmc_traffic.txt
 echo "pmc done"
+cd $R
+timeout -k 10 300 python tools/bench_rasterized.py > $O/bench_rasterized.json 2>> $O/bench.err
+timeout -k 10 600 python tools/bench_features.py > $O/bench_features.json 2>> $O/bench.err
+echo "secondary benches done"
 ls -la $O
