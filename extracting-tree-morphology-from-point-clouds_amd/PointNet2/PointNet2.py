@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import ops
 from ..Loss import MaskedPointLoss, point_wise_loss
 from ..Utils import cuda_cast
 from .blocks import (MLP, ConvHead, PointNetFeaturePropagation, PointNetSetAbstraction,
@@ -217,6 +218,7 @@ class PointNet2(nn.Module):
             del sem, off, mini_batch
         if return_loss:
             total_loss = float(total_dev)
+            ops.check_status(total_dev.device)   # at the sync the read-back just made: did any kernel give up?
         output = {"semantic_prediction_logits": self._average(sem_sum, sem_cnt),
                   "offset_predictions": self._average(off_sum, off_cnt)}
         if not return_loss:

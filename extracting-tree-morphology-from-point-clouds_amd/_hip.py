@@ -42,17 +42,17 @@ SIGNATURES = {
     "pn2_arch": (ctypes.c_char_p, []),
     "pn2_square_distance_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _int, _int, _int, _vp, _vp]),
     "pn2_fps_workspace_bytes": (_sz, [_int, _int, _int]),
-    "pn2_fps_f32": (_int, [_vp, _i64, _i64, _i64, _int, _int, _int, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pn2_fps_f32": (_int, [_vp, _i64, _i64, _i64, _int, _int, _int, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "pn2_ball_query_workspace_bytes": (_sz, [_int, _int, _int, _int]),
     "pn2_ball_query_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _int, _int, _int, _f32, _int, _vp, _vp,
                                   _sz, _vp]),
     "pn2_group_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _int, _int, _int, _int, _int, _int,
-                             _vp, _vp]),
+                             _vp, _vp, _vp]),
     "pn2_group_grad_f32": (_int, [_vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _vp]),
-    "pn2_gather_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _int, _int, _int, _int, _vp, _vp]),
+    "pn2_gather_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _int, _int, _int, _int, _vp, _vp, _vp]),
     "pn2_gather_grad_f32": (_int, [_vp, _vp, _int, _int, _int, _int, _vp, _vp]),
     "pn2_three_nn_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _int, _int, _int, _vp, _vp, _vp, _vp]),
-    "pn2_three_interpolate_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _int, _int, _int, _int, _vp, _i64, _i64, _vp]),
+    "pn2_three_interpolate_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _int, _int, _int, _int, _vp, _i64, _i64, _vp, _vp]),
     "pn2_three_interpolate_grad_workspace_bytes": (_sz, [_int, _int, _int, _int]),
     "pn2_three_interpolate_grad_f32": (_int, [_vp, _i64, _i64, _vp, _vp, _int, _int, _int, _int, _vp, _vp, _sz, _vp]),
     "pn2_prof_enable": (None, [_int]),
@@ -64,6 +64,8 @@ SIGNATURES = {
 }
 
 _lib = None
+ABI_VERSION = 2                      # PN2_ABI_VERSION of include/pn2_hip.h
+STATUS_FPS_HANDOFF, STATUS_FPS_ARRIVAL, STATUS_BAD_INDEX = 1, 2, 4   # PN2_STATUS_* bits
 
 
 def lib():
@@ -79,8 +81,8 @@ def lib():
             fn = getattr(cdll, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if cdll.pn2_version() != 1:
-            raise RuntimeError(f"libpn2hip ABI {cdll.pn2_version()} != 1")
+        if cdll.pn2_version() != ABI_VERSION:
+            raise RuntimeError(f"libpn2hip ABI {cdll.pn2_version()} != {ABI_VERSION}")
         _lib = cdll
     return _lib
 

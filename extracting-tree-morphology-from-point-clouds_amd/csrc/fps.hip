@@ -27,7 +27,30 @@ using u64 = unsigned long long;
 using f2 = __attribute__((ext_vector_type(2))) float;
 constexpr u64 kValid = 1ull << 63;
 constexpr int kMaxG = 64;
-constexpr unsigned kSpinLimit = 1u << 22;
+constexpr unsigned kSpinLimitDefault = 1u << 22;   // polls before a hand-off is declared dead (PN2_FPS_SPIN_LIMIT overrides)
+// status bits OR-ed into the caller's status word when a launch dies (include/pn2_hip.h: PN2_STATUS_*)
+constexpr int kStatusHandoff = PN2_STATUS_FPS_HANDOFF, kStatusArrival = PN2_STATUS_FPS_ARRIVAL;
+
+// Launch-wide knobs passed by value to every multi-workgroup kernel.
+struct Knobs {
+    unsigned spin_limit;   // bounded spins: a member that never shows up kills the launch instead of hanging it
+    int force_fallback;    // PN2_FPS_FORCE_FALLBACK: take the placement-independent grouping even when XCD-local groups exist
+    int* status;           // caller's sticky status word (device), may be null
+};
+
+// One poll of a bounded spin.  Returns false when the launch is dead: this waiter ran out of polls (it raises the
+// launch's error word, which every other waiter of the launch polls) or somebody else already did.  A dead launch is
+// never waited on again: every workgroup leaves at its next barrier, the rows it did not produce keep the -1 / NaN
+// fill written ahead of the kernel, and the caller's status word says why (ops.check_status raises on it).
+__device__ __forceinline__ bool spin_alive(unsigned& spins, const Knobs& kn, unsigned* err, int why) {
+    if (++spins > kn.spin_limit) {
+        atomicOr(err, 1u);
+        if (kn.status) atomicOr(kn.status, why);
+        return false;
+    }
+    if ((spins & 127u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+    return true;
+}
 #ifdef PN2_FPS_DIAG
 constexpr size_t kHdr = 256;
 #else
@@ -49,14 +72,17 @@ template <int PPT, int T>
 __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, int64_t sb, int64_t sn, int64_t sc,
                                                 int B, int N, int npoint, const int64_t* __restrict__ start,
                                                 int32_t* __restrict__ out_idx, float* __restrict__ out_xyz,
-                                                u64* gran, unsigned* err, int G, int groups) {
+                                                u64* gran, unsigned* err, int G, int groups, Knobs kn) {
     constexpr int NW = T / 64;
     __shared__ u64 s_key[2][NW];
     __shared__ float s_xyz[2][NW][3];
     __shared__ u64 s_win[2];
     __shared__ float s_wxyz[2][3];
+    __shared__ int s_dead;
 
     const int tid = threadIdx.x;
+    if (tid == 0) s_dead = 0;
+    __syncthreads();
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int g = blockIdx.x % G;
@@ -191,8 +217,8 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
                             const bool ok = ((v0 & kValid) != 0) & ((unsigned)(v1 >> 32) == tag) &
                                             ((unsigned)(v2 >> 32) == tag) & ((unsigned)(v3 >> 32) == tag);
                             if (ok) break;
-                            if (++spins > kSpinLimit) {  // a member never arrived: flag it and let the grid drain
-                                atomicOr(err, 1u);
+                            if (!spin_alive(spins, kn, err, kStatusHandoff)) {  // a member never arrived: the launch is dead
+                                s_dead = 1;
                                 v0 = kValid;
                                 break;
                             }
@@ -213,6 +239,7 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
                 STAMP(4);  // group reduce + LDS write
                 lds_barrier();
                 STAMP(5);  // barrier 2
+                if (s_dead) return;   // uniform: every thread reads the flag after the same barrier
                 k = s_win[buf];
                 nx = s_wxyz[buf][0];
                 ny = s_wxyz[buf][1];
@@ -261,7 +288,7 @@ __device__ __forceinline__ unsigned xcc_id() {
 
 // Phase 0 of the XCD-local kernels, run by one lane: which XCD did this workgroup land on, which group of G same-XCD
 // workgroups (or, failing that, of consecutive block ids) does it belong to.  s_role = {group or -1, rank, #groups, local}.
-__device__ void xcd_roles(XcdHeader* hdr, int G, int* s_role) {
+__device__ void xcd_roles(XcdHeader* hdr, int G, int* s_role, const Knobs& kn) {
         const unsigned x = xcc_id();
         const unsigned rank = atomicAdd(&hdr->cnt[x], 1u);
         __threadfence();
@@ -269,8 +296,7 @@ __device__ void xcd_roles(XcdHeader* hdr, int G, int* s_role) {
         unsigned spins = 0;
         bool ok = true;
         while (__hip_atomic_load(&hdr->arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
-            if (++spins > kSpinLimit) {
-                atomicOr(&hdr->err, 2u);
+            if (!spin_alive(spins, kn, &hdr->err, kStatusArrival)) {  // the grid is not co-resident (busy GPU)
                 ok = false;
                 break;
             }
@@ -284,7 +310,7 @@ __device__ void xcd_roles(XcdHeader* hdr, int G, int* s_role) {
             total += c;
         }
         int group = -1, grank = 0, ngroups = 0, local = 0;
-        if (ok && total > 0) {  // XCD-local groups
+        if (ok && total > 0 && !kn.force_fallback) {  // XCD-local groups
             local = 1;
             ngroups = total;
             if ((int)rank < mine * G) {
@@ -308,8 +334,9 @@ template <bool PERWAVE>
 __global__ __launch_bounds__(kXT) void fps_xcd_kernel(const float* __restrict__ xyz, int64_t sb, int64_t sn, int64_t sc,
                                                       int B, int N, int npoint, const int64_t* __restrict__ start,
                                                       int32_t* __restrict__ out_idx, float* __restrict__ out_xyz,
-                                                      u64* gran, XcdHeader* hdr, int G) {
+                                                      u64* gran, XcdHeader* hdr, int G, Knobs kn) {
     constexpr int T = kXT, NW = T / 64;
+    __shared__ int s_dead;
     __shared__ u64 s_key[2][NW];
     __shared__ float s_xyz[2][NW][3];
     __shared__ u64 s_win[2];
@@ -322,7 +349,10 @@ __global__ __launch_bounds__(kXT) void fps_xcd_kernel(const float* __restrict__ 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
     // ---- phase 0: where did this workgroup land?  (one lane; everything below is wave-uniform)
-    if (tid == 0) xcd_roles(hdr, G, s_role);
+    if (tid == 0) {
+        s_dead = 0;
+        xcd_roles(hdr, G, s_role, kn);
+    }
     __syncthreads();
     const int group = s_role[0], g = s_role[1], ngroups = s_role[2];
     const bool local = s_role[3] != 0;
@@ -458,8 +488,8 @@ __global__ __launch_bounds__(kXT) void fps_xcd_kernel(const float* __restrict__ 
                         }
                     }
                     if (__all(ok)) break;
-                    if (++spins > kSpinLimit) {
-                        if (lane == 0) atomicOr(&hdr->err, 1u);
+                    if (!spin_alive(spins, kn, &hdr->err, kStatusHandoff)) {  // wave-uniform
+                        s_dead = 1;
                         break;
                     }
                 }
@@ -476,6 +506,7 @@ __global__ __launch_bounds__(kXT) void fps_xcd_kernel(const float* __restrict__ 
             STAMP(4);
             lds_barrier();
             STAMP(5);
+            if (s_dead) return;
             k = s_win[buf];
             nx = s_wxyz[buf][0];
             ny = s_wxyz[buf][1];
@@ -543,8 +574,8 @@ __global__ __launch_bounds__(kXT) void fps_xcd_kernel(const float* __restrict__ 
                             const bool ok = ((v0 & kValid) != 0) & ((unsigned)(v1 >> 32) == tag) &
                                             ((unsigned)(v2 >> 32) == tag) & ((unsigned)(v3 >> 32) == tag);
                             if (ok) break;
-                            if (++spins > kSpinLimit) {
-                                atomicOr(&hdr->err, 1u);
+                            if (!spin_alive(spins, kn, &hdr->err, kStatusHandoff)) {
+                                s_dead = 1;
                                 v0 = kValid;
                                 break;
                             }
@@ -564,6 +595,7 @@ __global__ __launch_bounds__(kXT) void fps_xcd_kernel(const float* __restrict__ 
                 STAMP(4);
                 lds_barrier();
                 STAMP(5);
+                if (s_dead) return;
                 k = s_win[buf];
                 nx = s_wxyz[buf][0];
                 ny = s_wxyz[buf][1];
@@ -638,8 +670,9 @@ template <int PPT>
 __global__ __launch_bounds__(kXT) void fps_multi_kernel(const float* __restrict__ xyz, int64_t sb, int64_t sn, int64_t sc,
                                                         int B, int N, int npoint, const int64_t* __restrict__ start,
                                                         int32_t* __restrict__ out_idx, float* __restrict__ out_xyz,
-                                                        u64* gran, XcdHeader* hdr, int G) {
+                                                        u64* gran, XcdHeader* hdr, int G, Knobs kn) {
     constexpr int T = kXT, NW = T / 64;
+    __shared__ int s_dead;
     constexpr int kGran = 5;  // granules per member and round: {key, x, y, z} of its best point + the bound
     __shared__ u64 s_wkey[2][NW], s_wsec[2][NW];
     __shared__ float s_wxyz[2][NW][3];
@@ -650,7 +683,10 @@ __global__ __launch_bounds__(kXT) void fps_multi_kernel(const float* __restrict_
     __shared__ float s_px[PPT * kXT], s_py[PPT * kXT], s_pz[PPT * kXT];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) xcd_roles(hdr, G, s_role);
+    if (tid == 0) {
+        s_dead = 0;
+        xcd_roles(hdr, G, s_role, kn);
+    }
     __syncthreads();
     const int group = s_role[0], g = s_role[1], ngroups = s_role[2];
     const bool local = s_role[3] != 0;
@@ -782,6 +818,7 @@ __global__ __launch_bounds__(kXT) void fps_multi_kernel(const float* __restrict_
                 // ---- poll: lane l reads the five granules of members l and l + 64 (G <= 128)
                 u64 ek[2] = {0, 0}, hb = 0;
                 unsigned ex[2] = {0, 0}, ey[2] = {0, 0}, ez[2] = {0, 0};
+                bool dead = false;
                 {
                     const bool two = G > 64;  // wave-uniform
                     const u64* src0 = slot + (lane < G ? lane : 0);
@@ -807,8 +844,9 @@ __global__ __launch_bounds__(kXT) void fps_multi_kernel(const float* __restrict_
                             ex[1] = (unsigned)w1, ey[1] = (unsigned)w2, ez[1] = (unsigned)w3;
                         }
                         if (__all(ok)) break;
-                        if (++spins > kSpinLimit) {
-                            if (lane == 0) atomicOr(&hdr->err, 1u);
+                        if (!spin_alive(spins, kn, &hdr->err, kStatusHandoff)) {  // wave-uniform
+                            s_dead = 1;
+                            dead = true;
                             break;
                         }
                     }
@@ -856,7 +894,7 @@ __global__ __launch_bounds__(kXT) void fps_multi_kernel(const float* __restrict_
                     if (keep) acc = t + 1;
                 }
                 if (acc > npoint - count) acc = npoint - count;
-                if (g == 0 && lane < acc) {
+                if (g == 0 && lane < acc && !dead) {
                     const size_t o = (size_t)b * npoint + count + lane;
                     out_idx[o] = (int)(0xFFFFFFFFu - (unsigned)(s_ckey[buf][lane] & 0xFFFFFFFFull));
                     if (out_xyz)
@@ -867,6 +905,7 @@ __global__ __launch_bounds__(kXT) void fps_multi_kernel(const float* __restrict_
             }
             STAMP(5);  // group list + chain (wave 0) / wait (others)
             lds_barrier();
+            if (s_dead) return;   // dead launch: the samples accepted in this round were computed from garbage
             m = s_m[buf];
 #pragma unroll
             for (int t = 0; t < kMK; ++t) ccx[t] = s_cent[buf][t][0], ccy[t] = s_cent[buf][t][1], ccz[t] = s_cent[buf][t][2];
@@ -945,9 +984,25 @@ Config pick(int B, int N) {
 
 template <int PPT, int T>
 void launch(const Config& c, const float* xyz, int64_t sb, int64_t sn, int64_t sc, int B, int N, int npoint,
-            const int64_t* start, int32_t* out_idx, float* out_xyz, u64* gran, unsigned* err, hipStream_t s) {
+            const int64_t* start, int32_t* out_idx, float* out_xyz, u64* gran, unsigned* err, const Knobs& kn, hipStream_t s) {
     PN2_LAUNCH("fps", (double)B * (12.0 * N + 8.0 * npoint), 0, (fps_kernel<PPT, T>), dim3(c.groups * c.G), dim3(T), s, xyz, sb,
-               sn, sc, B, N, npoint, start, out_idx, out_xyz, gran, err, c.G, c.groups);
+               sn, sc, B, N, npoint, start, out_idx, out_xyz, gran, err, c.G, c.groups, kn);
+}
+
+Knobs knobs(int32_t* status) {
+    Knobs kn{kSpinLimitDefault, 0, status};
+    if (const char* e = getenv("PN2_FPS_SPIN_LIMIT")) kn.spin_limit = (unsigned)strtoul(e, nullptr, 10);   // test aid
+    kn.force_fallback = getenv("PN2_FPS_FORCE_FALLBACK") != nullptr;
+    return kn;
+}
+
+// Rows a dead launch never produced must not look like samples: indices are pre-filled with -1 and the centroids
+// with NaN (0xFFFFFFFF) ahead of every multi-workgroup launch (two small memset nodes; single-workgroup launches
+// cannot die).
+int prefill(int32_t* out_idx, float* out_xyz, int B, int npoint, hipStream_t s) {
+    PN2_HIP_CHECK(hipMemsetAsync(out_idx, 0xFF, (size_t)B * npoint * sizeof(int32_t), s));
+    if (out_xyz) PN2_HIP_CHECK(hipMemsetAsync(out_xyz, 0xFF, (size_t)B * npoint * 3 * sizeof(float), s));
+    return 0;
 }
 
 }  // namespace
@@ -966,8 +1021,9 @@ extern "C" size_t pn2_fps_workspace_bytes(int B, int N, int npoint) {
 
 extern "C" int pn2_fps_f32(const float* xyz, int64_t sb, int64_t sn, int64_t sc, int B, int N, int npoint,
                            const int64_t* start, int32_t* out_idx, float* out_xyz, void* workspace,
-                           size_t workspace_bytes, void* stream) {
+                           size_t workspace_bytes, int32_t* status, void* stream) {
     if (!xyz || !start || !out_idx || !workspace || B <= 0 || N <= 0 || npoint <= 0) return PN2_E_BADARG;
+    const Knobs kn = knobs(status);
     if (use_xcd_kernel(N)) {
         const size_t need = pn2_fps_workspace_bytes(B, N, npoint);
         if (workspace_bytes < need) return PN2_E_WORKSPACE;
@@ -975,25 +1031,26 @@ extern "C" int pn2_fps_f32(const float* xyz, int64_t sb, int64_t sn, int64_t sc,
         PN2_HIP_CHECK(hipMemsetAsync(workspace, 0, need, s));
         XcdHeader* hdr = (XcdHeader*)workspace;
         u64* gran = (u64*)((char*)workspace + sizeof(XcdHeader));
+        if (int st = prefill(out_idx, out_xyz, B, npoint, s)) return st;
         if (use_multi_pick(N, npoint)) {
             const int ppt = multi_ppt(N), G = multi_group_size(N);
             const double fb = (double)B * (12.0 * N + 8.0 * npoint);
             if (ppt == 4)
                 PN2_LAUNCH("fps", fb, 0, (fps_multi_kernel<4>), dim3(kXGrid), dim3(kXT), s, xyz, sb, sn, sc, B, N, npoint, start,
-                           out_idx, out_xyz, gran, hdr, G);
+                           out_idx, out_xyz, gran, hdr, G, kn);
             else if (ppt == 8)
                 PN2_LAUNCH("fps", fb, 0, (fps_multi_kernel<8>), dim3(kXGrid), dim3(kXT), s, xyz, sb, sn, sc, B, N, npoint, start,
-                           out_idx, out_xyz, gran, hdr, G);
+                           out_idx, out_xyz, gran, hdr, G, kn);
             else
                 PN2_LAUNCH("fps", fb, 0, (fps_multi_kernel<16>), dim3(kXGrid), dim3(kXT), s, xyz, sb, sn, sc, B, N, npoint, start,
-                           out_idx, out_xyz, gran, hdr, G);
+                           out_idx, out_xyz, gran, hdr, G, kn);
         }
         else if (xcd_perwave(N))
             PN2_LAUNCH("fps", (double)B * (12.0 * N + 8.0 * npoint), 0, (fps_xcd_kernel<true>), dim3(kXGrid), dim3(kXT), s, xyz, sb,
-                       sn, sc, B, N, npoint, start, out_idx, out_xyz, gran, hdr, xcd_group_size(N));
+                       sn, sc, B, N, npoint, start, out_idx, out_xyz, gran, hdr, xcd_group_size(N), kn);
         else
             PN2_LAUNCH("fps", (double)B * (12.0 * N + 8.0 * npoint), 0, (fps_xcd_kernel<false>), dim3(kXGrid), dim3(kXT), s, xyz, sb,
-                       sn, sc, B, N, npoint, start, out_idx, out_xyz, gran, hdr, xcd_group_size(N));
+                       sn, sc, B, N, npoint, start, out_idx, out_xyz, gran, hdr, xcd_group_size(N), kn);
         PN2_LAUNCH_CHECK();
         return 0;
     }
@@ -1005,9 +1062,11 @@ extern "C" int pn2_fps_f32(const float* xyz, int64_t sb, int64_t sn, int64_t sc,
     PN2_HIP_CHECK(hipMemsetAsync(workspace, 0, need, s));
     unsigned* err = (unsigned*)workspace;
     u64* gran = (u64*)((char*)workspace + kHdr);
+    if (c.G > 1)
+        if (int st = prefill(out_idx, out_xyz, B, npoint, s)) return st;
 #define PN2_FPS_CASE(P, T_)                                                                                  \
     if (c.ppt == P && c.t == T_) {                                                                           \
-        launch<P, T_>(c, xyz, sb, sn, sc, B, N, npoint, start, out_idx, out_xyz, gran, err, s);              \
+        launch<P, T_>(c, xyz, sb, sn, sc, B, N, npoint, start, out_idx, out_xyz, gran, err, kn, s);          \
     } else
     PN2_FPS_CASE(1, 256)
     PN2_FPS_CASE(2, 256)

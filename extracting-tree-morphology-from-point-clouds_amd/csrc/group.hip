@@ -11,18 +11,27 @@ namespace {
 
 constexpr int kBlock = 256;
 
+// Indices handed to a gather are data, not trusted: one outside [0, N) is not followed (the element is taken from row 0 and the
+// caller's status word gets PN2_STATUS_BAD_INDEX) instead of faulting the GPU -- e.g. the -1 rows a dead FPS launch
+// leaves behind.  The reference asserts the range on the host (pointnet2_utils.py:54), which costs a sync per call.
+__device__ __forceinline__ int checked(int j, int N, int32_t* status) {
+    if ((unsigned)j < (unsigned)N) return j;
+    if (status) atomicOr(status, PN2_STATUS_BAD_INDEX);
+    return 0;
+}
+
 __global__ __launch_bounds__(kBlock) void group_kernel(const float* __restrict__ xyz, int64_t sb, int64_t sn, int64_t sc,
                                                        const float* __restrict__ new_xyz, const float* __restrict__ feats,
                                                        int64_t fb, int64_t fn, int64_t fc, const int32_t* __restrict__ idx,
                                                        int B, int N, int S, int K, int D, int xyz_last,
-                                                       float* __restrict__ out, long long total) {
+                                                       float* __restrict__ out, long long total, int32_t* status) {
     const int C = 3 + D;
     for (long long e = (long long)blockIdx.x * kBlock + threadIdx.x; e < total; e += (long long)gridDim.x * kBlock) {
         const long long r = e / C;  // (b, s, k)
         const int c = (int)(e - r * C);
         const long long bs = r / K;
         const int b = (int)(bs / S);
-        const int j = idx[r];
+        const int j = checked(idx[r], N, status);
         const int cx = xyz_last ? c - D : c;  // coordinate channel if in [0,3)
         float v;
         if (cx >= 0 && cx < 3) {
@@ -44,6 +53,7 @@ __global__ __launch_bounds__(kBlock) void group_grad_kernel(const float* __restr
         const int cf = (int)(e - r * D);
         const int b = (int)(r / ((long long)S * K));
         const int j = idx[r];
+        if ((unsigned)j >= (unsigned)N) continue;   // flagged by the forward pass
         const float g = dout[r * C + (xyz_last ? cf : cf + 3)];
         atomicAdd(dfeats + ((int64_t)b * N + j) * D + cf, g);
     }
@@ -51,12 +61,12 @@ __global__ __launch_bounds__(kBlock) void group_grad_kernel(const float* __restr
 
 __global__ __launch_bounds__(kBlock) void gather_kernel(const float* __restrict__ points, int64_t pb, int64_t pn, int64_t pc,
                                                         const int32_t* __restrict__ idx, int B, int N, int S, int C,
-                                                        float* __restrict__ out, long long total) {
+                                                        float* __restrict__ out, long long total, int32_t* status) {
     for (long long e = (long long)blockIdx.x * kBlock + threadIdx.x; e < total; e += (long long)gridDim.x * kBlock) {
         const long long r = e / C;
         const int c = (int)(e - r * C);
         const int b = (int)(r / S);
-        out[e] = points[(int64_t)b * pb + (int64_t)idx[r] * pn + c * pc];
+        out[e] = points[(int64_t)b * pb + (int64_t)checked(idx[r], N, status) * pn + c * pc];
     }
 }
 
@@ -67,7 +77,9 @@ __global__ __launch_bounds__(kBlock) void gather_grad_kernel(const float* __rest
         const long long r = e / C;
         const int c = (int)(e - r * C);
         const int b = (int)(r / S);
-        atomicAdd(dpoints + ((int64_t)b * N + idx[r]) * C + c, dout[e]);
+        const int j = idx[r];
+        if ((unsigned)j >= (unsigned)N) continue;   // flagged by the forward pass
+        atomicAdd(dpoints + ((int64_t)b * N + j) * C + c, dout[e]);
     }
 }
 
@@ -80,12 +92,12 @@ inline unsigned grid_for(long long total) {
 
 extern "C" int pn2_group_f32(const float* xyz, int64_t sb, int64_t sn, int64_t sc, const float* new_xyz,
                              const float* feats, int64_t fb, int64_t fn, int64_t fc, const int32_t* idx, int B, int N,
-                             int S, int K, int D, int xyz_last, float* out, void* stream) {
+                             int S, int K, int D, int xyz_last, float* out, int32_t* status, void* stream) {
     if (!xyz || !new_xyz || !idx || !out || B <= 0 || N <= 0 || S <= 0 || K <= 0 || D < 0 || (D > 0 && !feats))
         return PN2_E_BADARG;
     const long long total = (long long)B * S * K * (3 + D);
     PN2_LAUNCH("group", 8.0 * total + 4.0 * B * S * K, 0, group_kernel, dim3(grid_for(total)), dim3(kBlock), (hipStream_t)stream,
-               xyz, sb, sn, sc, new_xyz, feats, fb, fn, fc, idx, B, N, S, K, D, xyz_last, out, total);
+               xyz, sb, sn, sc, new_xyz, feats, fb, fn, fc, idx, B, N, S, K, D, xyz_last, out, total, status);
     PN2_LAUNCH_CHECK();
     return 0;
 }
@@ -103,11 +115,11 @@ extern "C" int pn2_group_grad_f32(const float* dout, const int32_t* idx, int B, 
 }
 
 extern "C" int pn2_gather_f32(const float* points, int64_t pb, int64_t pn, int64_t pc, const int32_t* idx, int B,
-                              int N, int S, int C, float* out, void* stream) {
+                              int N, int S, int C, float* out, int32_t* status, void* stream) {
     if (!points || !idx || !out || B <= 0 || N <= 0 || S <= 0 || C <= 0) return PN2_E_BADARG;
     const long long total = (long long)B * S * C;
     PN2_LAUNCH("gather", 8.0 * total + 4.0 * B * S, 0, gather_kernel, dim3(grid_for(total)), dim3(kBlock), (hipStream_t)stream,
-               points, pb, pn, pc, idx, B, N, S, C, out, total);
+               points, pb, pn, pc, idx, B, N, S, C, out, total, status);
     PN2_LAUNCH_CHECK();
     return 0;
 }

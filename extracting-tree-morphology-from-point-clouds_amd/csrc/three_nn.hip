@@ -134,15 +134,22 @@ __device__ __forceinline__ float interp1(float a, float b, float c, float w0, fl
 template <int V>
 __global__ __launch_bounds__(kBlock) void three_interpolate_kernel(const float* __restrict__ points2, int64_t pb, int64_t pn,
                                                                    int64_t pc, const int32_t* __restrict__ idx,
-                                                                   const float* __restrict__ w, int N, int D,
+                                                                   const float* __restrict__ w, int N, int S, int D,
                                                                    float* __restrict__ out, int64_t out_stride,
-                                                                   int64_t out_offset, long long total) {
+                                                                   int64_t out_offset, long long total, int32_t* status) {
     const int DV = D / V;
     for (long long e = (long long)blockIdx.x * kBlock + threadIdx.x; e < total; e += (long long)gridDim.x * kBlock) {
         const long long r = e / DV;  // (b, n)
         const int c = (int)(e - r * DV) * V;
         const int b = (int)(r / N);
-        const int j0 = idx[r * 3], j1 = idx[r * 3 + 1], j2 = idx[r * 3 + 2];
+        int j0 = idx[r * 3], j1 = idx[r * 3 + 1], j2 = idx[r * 3 + 2];
+        if (((unsigned)j0 >= (unsigned)S) | ((unsigned)j1 >= (unsigned)S) | ((unsigned)j2 >= (unsigned)S)) {
+            // untrusted index: do not follow it (row 0 instead) and tell the caller (PN2_STATUS_BAD_INDEX)
+            if (status) atomicOr(status, PN2_STATUS_BAD_INDEX);
+            j0 = (unsigned)j0 < (unsigned)S ? j0 : 0;
+            j1 = (unsigned)j1 < (unsigned)S ? j1 : 0;
+            j2 = (unsigned)j2 < (unsigned)S ? j2 : 0;
+        }
         const float w0 = w[r * 3], w1 = w[r * 3 + 1], w2 = w[r * 3 + 2];
         const float* base = points2 + (int64_t)b * pb;
         float* o = out + r * out_stride + out_offset + c;
@@ -173,6 +180,9 @@ __global__ __launch_bounds__(kBlock) void three_interpolate_kernel(const float* 
 // workgroup first counts its contiguous share of one cloud's pairs in LDS and then adds S totals to global memory.
 // blockIdx.y = cloud, blockIdx.x = share.
 constexpr int TIG_T = 1024;
+// the backward kernels see the indices the forward pass already validated (and flagged); clamping keeps a bad one from
+// becoming an out-of-bounds LDS / global access
+__device__ __forceinline__ int clamp_idx(int j, int S) { return (unsigned)j < (unsigned)S ? j : 0; }
 __global__ __launch_bounds__(TIG_T) void tig_count_kernel(const int32_t* __restrict__ idx, int N, int S, int per_block,
                                                           int* __restrict__ hist) {
     extern __shared__ int lh[];  // [S]
@@ -181,7 +191,7 @@ __global__ __launch_bounds__(TIG_T) void tig_count_kernel(const int32_t* __restr
     __syncthreads();
     const long long p0 = (long long)blockIdx.x * per_block, p1 = p0 + per_block < 3LL * N ? p0 + per_block : 3LL * N;
     const int32_t* ib = idx + (long long)b * 3 * N;
-    for (long long e = p0 + threadIdx.x; e < p1; e += TIG_T) atomicAdd(&lh[ib[e]], 1);
+    for (long long e = p0 + threadIdx.x; e < p1; e += TIG_T) atomicAdd(&lh[clamp_idx(ib[e], S)], 1);
     __syncthreads();
     for (int e = threadIdx.x; e < S; e += TIG_T)
         if (lh[e]) atomicAdd(hist + (long long)b * S + e, lh[e]);
@@ -243,7 +253,7 @@ __global__ __launch_bounds__(TIG_T) void tig_fill_kernel(const int32_t* __restri
     const long long p0 = (long long)blockIdx.x * per_block, p1 = p0 + per_block < 3LL * N ? p0 + per_block : 3LL * N;
     const int32_t* ib = idx + (long long)b * 3 * N;
     const float* wb = w + (long long)b * 3 * N;
-    for (long long e = p0 + threadIdx.x; e < p1; e += TIG_T) atomicAdd(&lh[ib[e]], 1);
+    for (long long e = p0 + threadIdx.x; e < p1; e += TIG_T) atomicAdd(&lh[clamp_idx(ib[e], S)], 1);
     __syncthreads();
     for (int e = threadIdx.x; e < S; e += TIG_T) {
         const int c = lh[e];
@@ -251,7 +261,7 @@ __global__ __launch_bounds__(TIG_T) void tig_fill_kernel(const int32_t* __restri
     }
     __syncthreads();
     for (long long e = p0 + threadIdx.x; e < p1; e += TIG_T) {
-        const int pos = atomicAdd(&lh[ib[e]], 1);
+        const int pos = atomicAdd(&lh[clamp_idx(ib[e], S)], 1);
         list[pos] = make_int2((int)((long long)b * N + e / 3), __float_as_int(wb[e]));
     }
 }
@@ -300,7 +310,7 @@ __global__ __launch_bounds__(kBlock) void three_interpolate_grad_global_kernel(c
         const float g = dout[r * out_stride + out_offset + c];
         float* base = dpoints2 + (int64_t)b * S * D + c;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) atomicAdd(base + (int64_t)idx[r * 3 + k] * D, __fmul_rn(g, w[r * 3 + k]));
+        for (int k = 0; k < 3; ++k) atomicAdd(base + (int64_t)clamp_idx(idx[r * 3 + k], S) * D, __fmul_rn(g, w[r * 3 + k]));
     }
 }
 
@@ -365,7 +375,7 @@ extern "C" int pn2_square_distance_f32(const float* src, int64_t ab, int64_t an,
 
 extern "C" int pn2_three_interpolate_f32(const float* points2, int64_t pb, int64_t pn, int64_t pc, const int32_t* idx,
                                          const float* w, int B, int N, int S, int D, float* out, int64_t out_stride,
-                                         int64_t out_offset, void* stream) {
+                                         int64_t out_offset, int32_t* status, void* stream) {
     if (!points2 || !idx || !w || !out || B <= 0 || N <= 0 || S <= 0 || D <= 0 || out_stride < out_offset + D)
         return PN2_E_BADARG;
     const bool vec = pc == 1 && D % 4 == 0 && pn % 4 == 0 && pb % 4 == 0 && out_stride % 4 == 0 && out_offset % 4 == 0 &&
@@ -375,11 +385,11 @@ extern "C" int pn2_three_interpolate_f32(const float* points2, int64_t pb, int64
     if (vec) {
         const long long total = (long long)B * N * (D / 4);
         PN2_LAUNCH("three_interpolate", ti_bytes, 0, (three_interpolate_kernel<4>), dim3(grid_for(total)), dim3(kBlock), s,
-                   points2, pb, pn, pc, idx, w, N, D, out, out_stride, out_offset, total);
+                   points2, pb, pn, pc, idx, w, N, S, D, out, out_stride, out_offset, total, status);
     } else {
         const long long total = (long long)B * N * D;
         PN2_LAUNCH("three_interpolate", ti_bytes, 0, (three_interpolate_kernel<1>), dim3(grid_for(total)), dim3(kBlock), s,
-                   points2, pb, pn, pc, idx, w, N, D, out, out_stride, out_offset, total);
+                   points2, pb, pn, pc, idx, w, N, S, D, out, out_stride, out_offset, total, status);
     }
     PN2_LAUNCH_CHECK();
     return 0;

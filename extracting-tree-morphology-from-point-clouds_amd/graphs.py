@@ -25,14 +25,21 @@ class GraphedTrainStep:
             for _ in range(warmup):
                 self.feed.begin_pass()
                 step_fn()
+                side.synchronize()      # the pinned start-index slots are rewritten by the next pass
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with self.feed:
             with torch.cuda.graph(self.graph):
                 self.loss = step_fn()
+        self.done = torch.cuda.Event()
 
     def __call__(self):
+        # The replay's host-to-device copy nodes read the pinned slots when they EXECUTE, not when they are enqueued:
+        # the previous replay must have consumed its draws before they are overwritten (otherwise two steps share
+        # start indices and the reference's RNG order is lost).
+        self.done.synchronize()
         self.feed.redraw()
         self.graph.replay()
+        self.done.record()
         return self.loss

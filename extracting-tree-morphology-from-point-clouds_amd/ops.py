@@ -26,6 +26,42 @@ def _workspace(nbytes, device):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
 
+# One sticky int32 status word per device (include/pn2_hip.h: PN2_STATUS_*).  Kernels OR a bit in when they gave up
+# instead of producing results -- an FPS hand-off that timed out on a busy GPU, an index outside its range -- and leave
+# -1 / NaN behind; nothing is read back on the hot path.  `check_status()` reads the word (a device sync) and raises:
+# call it where the host synchronises anyway (the loss read-back of a step, the end of an inference pass, a test).
+_status_words = {}
+_STATUS_TEXT = {_hip.STATUS_FPS_HANDOFF: "farthest_point_sample: a workgroup hand-off timed out (GPU shared with another "
+                                         "kernel?); the unfinished rows hold -1 / NaN",
+                _hip.STATUS_FPS_ARRIVAL: "farthest_point_sample: the launch's workgroups were not co-resident",
+                _hip.STATUS_BAD_INDEX: "a gather was handed an index outside [0, N)"}
+
+
+def status_word(device):
+    dev = torch.device(device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    t = _status_words.get(dev)
+    if t is None:
+        t = _status_words[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+    return t
+
+
+def check_status(device=None, clear=True):
+    """Raise RuntimeError if any kernel since the last check reported a failure on `device` (default: every device
+    used so far).  Synchronises the device."""
+    words = [status_word(device)] if device is not None else list(_status_words.values())
+    bad = []
+    for t in words:
+        v = int(t.item())
+        if v:
+            if clear:
+                t.zero_()
+            bad += [f"{t.device}: {text}" for bit, text in _STATUS_TEXT.items() if v & bit]
+    if bad:
+        raise RuntimeError("libpn2hip reported failed kernels -- " + "; ".join(bad))
+
+
 # ----------------------------------------------------------------------------------------------- forward-only ops
 def square_distance(src, dst):
     """[B,N,3] x [B,M,3] -> [B,N,M], the reference's expanded form (pointnet2_utils.py:21-42)."""
@@ -53,11 +89,10 @@ def furthest_point_sample(xyz, npoint, start):
     ws = _workspace(nbytes, xyz.device)
     start = start.to(device=xyz.device, dtype=torch.int64).contiguous()
     _hip.call("farthest_point_sample", lib.pn2_fps_f32, xyz.data_ptr(), *_strides3(xyz), B, N, npoint, start.data_ptr(),
-              idx.data_ptr(), new_xyz.data_ptr(), ws.data_ptr(), ws.numel(), _hip.stream_ptr(),
-              nbytes=B * (12 * N + 8 * npoint))
+              idx.data_ptr(), new_xyz.data_ptr(), ws.data_ptr(), ws.numel(), status_word(xyz.device).data_ptr(),
+              _hip.stream_ptr(), nbytes=B * (12 * N + 8 * npoint))
     if _DEBUG:
-        if int(ws[:4].view(torch.int32)[0]) != 0:
-            raise RuntimeError("farthest_point_sample: a workgroup hand-off timed out")
+        check_status(xyz.device)
     return idx, new_xyz
 
 
@@ -96,7 +131,9 @@ def three_nn(xyz1, xyz2, want_dist=False):
 
 
 def _check_idx(idx, n, what):
-    if _DEBUG and idx.numel():  # the reference asserts the range on every call (pointnet2_utils.py:54); it costs a sync
+    # The reference asserts the range on every call (pointnet2_utils.py:54), which costs a device sync.  The kernels do
+    # not follow an out-of-range index and flag it in the status word (check_status()); PN2_DEBUG=1 asserts right here.
+    if _DEBUG and idx.numel():
         lo, hi = int(idx.min()), int(idx.max())
         if lo < 0 or hi >= n:
             raise AssertionError(f"{what}: index out of range [{lo}, {hi}] for N={n}")
@@ -120,7 +157,7 @@ class GatherPoints(torch.autograd.Function):
         S = idx32.numel() // B
         out = torch.empty(*idx.shape, C, dtype=torch.float32, device=points.device)
         _hip.call("index_points", _hip.lib().pn2_gather_f32, points.data_ptr(), *_strides3(points), idx32.data_ptr(), B, N,
-                  S, C, out.data_ptr(), _hip.stream_ptr(), nbytes=B * S * (8 + 8 * C))
+                  S, C, out.data_ptr(), status_word(points.device).data_ptr(), _hip.stream_ptr(), nbytes=B * S * (8 + 8 * C))
         ctx.save_for_backward(idx32)
         ctx.dims = (B, N, S, C)
         return out
@@ -156,8 +193,8 @@ class GroupPoints(torch.autograd.Function):
             D, fptr, fs = feats.shape[2], feats.data_ptr(), _strides3(feats)
         out = torch.empty(B, S, K, 3 + D, dtype=torch.float32, device=xyz.device)
         _hip.call("group_points", _hip.lib().pn2_group_f32, xyz.data_ptr(), *_strides3(xyz), new_xyz.data_ptr(), fptr, *fs,
-                  idx32.data_ptr(), B, N, S, K, D, int(bool(xyz_last)), out.data_ptr(), _hip.stream_ptr(),
-                  nbytes=B * S * K * (8 + 8 * (3 + D)))
+                  idx32.data_ptr(), B, N, S, K, D, int(bool(xyz_last)), out.data_ptr(), status_word(xyz.device).data_ptr(),
+                  _hip.stream_ptr(), nbytes=B * S * K * (8 + 8 * (3 + D)))
         ctx.save_for_backward(idx32)
         ctx.dims = (B, N, S, K, D, int(bool(xyz_last)))
         return out
@@ -193,8 +230,8 @@ class ThreeInterpolateConcat(torch.autograd.Function):
         if D1:
             out[:, :, :D1].copy_(points1)
         _hip.call("three_interpolate", _hip.lib().pn2_three_interpolate_f32, points2.data_ptr(), *_strides3(points2),
-                  idx32.data_ptr(), w.data_ptr(), B, N, S, D2, out.data_ptr(), D1 + D2, D1, _hip.stream_ptr(),
-                  nbytes=B * N * (3 * 12 + 4 * D2) + 4 * B * S * D2)
+                  idx32.data_ptr(), w.data_ptr(), B, N, S, D2, out.data_ptr(), D1 + D2, D1,
+                  status_word(points2.device).data_ptr(), _hip.stream_ptr(), nbytes=B * N * (3 * 12 + 4 * D2) + 4 * B * S * D2)
         ctx.save_for_backward(idx32, w)
         ctx.dims = (B, N, S, D1, D2)
         return out

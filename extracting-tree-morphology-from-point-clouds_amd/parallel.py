@@ -34,7 +34,9 @@ class FlatGradAllReduce:
     """Owns one contiguous fp32 buffer that every parameter's ``.grad`` is a view of, so the per-step
     exchange is a single collective with no packing copies."""
 
-    def __init__(self, module):
+    def __init__(self, module, broadcast=True):
+        if broadcast:
+            broadcast_module_state(module)
         self.params = [p for p in module.parameters() if p.requires_grad]
         total = sum(p.numel() for p in self.params)
         dev = self.params[0].device
@@ -57,6 +59,27 @@ class FlatGradAllReduce:
             if average:
                 self.flat.div_(dist.get_world_size())
         return self.flat
+
+
+def broadcast_module_state(module, src=0):
+    """Make every replica start from rank `src`'s parameters AND buffers (BatchNorm running statistics, counters):
+    replica equality must not depend on every rank having seeded its initialisation identically.  A no-op without
+    an initialised process group."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t, src=src)
+
+
+def allreduce_mean(values, device):
+    """Mean over ranks of a few host scalars (validation losses): every rank then takes the same early-stopping and
+    checkpoint decisions."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return list(values)
+    t = torch.tensor(list(values), dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return (t / dist.get_world_size()).tolist()
 
 
 def shard_range(n_items, rank, world):

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 from torch.utils.data import DataLoader
 
-from . import parallel
+from . import ops, parallel
 
 
 def _bar(iterable, parent=None, comment=""):
@@ -60,6 +60,8 @@ def train(model, train_loader, optimizer, scheduler, scaler, epoch, mb, raster_h
         torch.nn.utils.clip_grad_norm_(model.parameters(), True, norm_type=2)
         scaler.step(optimizer)
         scaler.update()
+        if torch.cuda.is_available():
+            ops.check_status()       # the loss read-back above already synchronised: a kernel that gave up raises here
         since_flush += 1
         if since_flush % 5 == 0 and torch.cuda.is_available():
             torch.cuda.empty_cache()
@@ -103,6 +105,9 @@ def run_training(model, train_loader: DataLoader, val_loader: DataLoader, optimi
         tr = train(model, train_loader, optimizer, scheduler, scaler, epoch, None, raster_hierarchical,
                    minibatch_streaming, grad_sync=grad_sync)
         va = validate(model, val_loader, epoch, None, raster_hierarchical, minibatch_streaming)
+        if distributed:              # every rank validated its own shard: decide on the mean, identically everywhere
+            dev = next(model.parameters()).device
+            tr, va = tuple(parallel.allreduce_mean(tr, dev)), tuple(parallel.allreduce_mean(va, dev))
         msg = (f"Epoch {epoch + 1}/{epochs} | Train Total Loss: {tr[0]:.4f}, Val Total Loss: {va[0]:.4f}, "
                f"Train Offset Loss: {tr[1]:.4f}, Val Offset Loss: {va[1]:.4f}, "
                f"Train Semantic Loss: {tr[2]:.4f}, Val Semantic Loss: {va[2]:.4f} | {time.time() - t0:.1f} s")

@@ -31,7 +31,14 @@ extern "C" {
 #define PN2_E_BADARG (-1)   /* null pointer / non-positive size / unsupported size */
 #define PN2_E_WORKSPACE (-2) /* workspace too small */
 
-#define PN2_ABI_VERSION 1
+#define PN2_ABI_VERSION 2
+
+/* Bits of the caller-owned sticky STATUS word (a device int32 the caller zeroes once and reads at a synchronisation
+ * point it has anyway, e.g. the loss read-back; the Python mirror: ops.check_status()).  A kernel ORs a bit in when it
+ * gave up instead of producing results -- the rows it did not produce hold -1 indices / NaN coordinates. */
+#define PN2_STATUS_FPS_HANDOFF 1 /* farthest_point_sample: a workgroup of a cloud's group never delivered its candidate */
+#define PN2_STATUS_FPS_ARRIVAL 2 /* farthest_point_sample: the launch's workgroups were not co-resident (busy GPU) */
+#define PN2_STATUS_BAD_INDEX 4   /* a gather / scatter kernel was handed an index outside [0, N) and skipped it */
 
 /* ABI version of the loaded library (compare with PN2_ABI_VERSION). */
 int pn2_version(void);
@@ -53,11 +60,19 @@ int pn2_square_distance_f32(const float *src, int64_t ab, int64_t an, int64_t ac
  *   out_idx  [B,npoint] int32
  *   out_xyz  [B,npoint,3] f32 or NULL -- the gathered centroids (index_points(xyz, idx), line 154)
  *   workspace: pn2_fps_workspace_bytes(B,N,npoint) bytes, contents irrelevant on entry.
+ *   status   device int32 or NULL (PN2_STATUS_*).  Clouds of more than 8192 points are sampled by several
+ *            workgroups that hand candidates to each other through memory; every wait is bounded (PN2_FPS_SPIN_LIMIT
+ *            polls, default 2^22).  When a wait expires the whole launch stops within microseconds, the rows not yet
+ *            produced keep the -1 (out_idx) / NaN (out_xyz) fill written ahead of the kernel, and the status word
+ *            gets PN2_STATUS_FPS_HANDOFF / _ARRIVAL.  Environment switches (read per call; all paths produce
+ *            identical indices): PN2_FPS_NO_XCD (consecutive-block groups, write-through hand-off), PN2_FPS_NO_MULTI
+ *            (one sample per exchange), PN2_FPS_FORCE_FALLBACK (the XCD-local kernels with their placement-independent
+ *            grouping).
  */
 size_t pn2_fps_workspace_bytes(int B, int N, int npoint);
 int pn2_fps_f32(const float *xyz, int64_t sb, int64_t sn, int64_t sc, int B, int N, int npoint,
                 const int64_t *start, int32_t *out_idx, float *out_xyz, void *workspace,
-                size_t workspace_bytes, void *stream);
+                size_t workspace_bytes, int32_t *status, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * query_ball_point                 replaces Modules/PointNet2/pointnet2_utils.py:92-136
@@ -75,10 +90,13 @@ int pn2_ball_query_f32(const float *xyz, int64_t sb, int64_t sn, int64_t sc, con
  * group_points (+ centring + concat)   replaces index_points x2 and lines 156-161 of sample_and_group
  *   out [B,S,K,3+D]: channels [xyz - new_xyz, feats] or, with xyz_last != 0, [feats, xyz - new_xyz]
  *   (the MSG order, blocks.py:143-146).  feats may be NULL with D = 0.
+ *   status (device int32 or NULL): an index outside [0,N) is not followed (row 0 is read instead) and sets
+ *   PN2_STATUS_BAD_INDEX -- the sync-free form of the reference's host-side range assert (pointnet2_utils.py:54).
+ *   The same holds for pn2_gather_f32 and pn2_three_interpolate_f32; the *_grad entry points skip such entries.
  */
 int pn2_group_f32(const float *xyz, int64_t sb, int64_t sn, int64_t sc, const float *new_xyz,
                   const float *feats, int64_t fb, int64_t fn, int64_t fc, const int32_t *idx, int B, int N,
-                  int S, int K, int D, int xyz_last, float *out, void *stream);
+                  int S, int K, int D, int xyz_last, float *out, int32_t *status, void *stream);
 
 /* gradient w.r.t. feats: dfeats [B,N,D] (dense, zeroed by the call) += dout[..., feature channels] */
 int pn2_group_grad_f32(const float *dout, const int32_t *idx, int B, int N, int S, int K, int D,
@@ -86,7 +104,7 @@ int pn2_group_grad_f32(const float *dout, const int32_t *idx, int B, int N, int 
 
 /* plain index_points: out[b][s][:] = points[b][idx[b][s]][:]   (pointnet2_utils.py:45-63) */
 int pn2_gather_f32(const float *points, int64_t pb, int64_t pn, int64_t pc, const int32_t *idx, int B, int N,
-                   int S, int C, float *out, void *stream);
+                   int S, int C, float *out, int32_t *status, void *stream);
 int pn2_gather_grad_f32(const float *dout, const int32_t *idx, int B, int N, int S, int C, float *dpoints,
                         void *stream);
 
@@ -149,7 +167,7 @@ int pn2_knn_radius_grid_f64(const double *points, int N, int k, double r2, int32
  */
 int pn2_three_interpolate_f32(const float *points2, int64_t pb, int64_t pn, int64_t pc, const int32_t *idx,
                               const float *w, int B, int N, int S, int D, float *out, int64_t out_stride,
-                              int64_t out_offset, void *stream);
+                              int64_t out_offset, int32_t *status, void *stream);
 /* dpoints2 [B,S,D] (dense, zeroed by the call) += w * dout[:, out_offset : out_offset+D]
  * workspace: pn2_three_interpolate_grad_workspace_bytes(B,N,S,D) bytes (large calls bucket the contributions by
  * destination before summing them). */

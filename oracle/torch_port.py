@@ -74,9 +74,12 @@ def sample_and_group(npoint, radius, nsample, xyz, points, start=None, xyz_last=
     return new_xyz, torch.cat([grouped, rel] if xyz_last else [rel, grouped], dim=-1)
 
 
+STABLE_SORT = False   # tests set this to compare against the product's documented three-NN tie rule (lower index first)
+
+
 def three_nn_interpolate(xyz1, xyz2, points2):
     B, N, _ = xyz1.shape
-    d, idx = square_distance(xyz1, xyz2).sort(dim=-1)           # blocks.py:195, full sort over S
+    d, idx = square_distance(xyz1, xyz2).sort(dim=-1, stable=STABLE_SORT)   # blocks.py:195, full sort over S
     d, idx = d[:, :, :3], idx[:, :, :3]
     rec = 1.0 / torch.clamp(d, min=1e-6)
     w = rec / rec.sum(dim=2, keepdim=True)

@@ -39,7 +39,7 @@ def test_binding_table_matches_header():
 
 def test_version_and_arch(cdll):
     cdll.pn2_arch.restype = ctypes.c_char_p
-    assert cdll.pn2_version() == 1
+    assert cdll.pn2_version() == 2
     assert cdll.pn2_arch() == b"gfx950"
 
 
@@ -62,7 +62,8 @@ def test_bad_arguments_are_rejected_on_the_host(cdll):
     null = ctypes.c_void_p(None)
     i64 = ctypes.c_int64
     # null pointers -> PN2_E_BADARG before any HIP call
-    assert cdll.pn2_fps_f32(null, i64(0), i64(0), i64(0), 1, 8, 4, null, null, null, null, ctypes.c_size_t(0), null) == -1
+    assert cdll.pn2_fps_f32(null, i64(0), i64(0), i64(0), 1, 8, 4, null, null, null, null, ctypes.c_size_t(0), null,
+                            null) == -1
     assert cdll.pn2_three_nn_f32(null, i64(0), i64(0), i64(0), null, i64(0), i64(0), i64(0), 1, 8, 3, null, null, null,
                                  null) == -1
 

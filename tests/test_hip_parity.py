@@ -357,7 +357,17 @@ def close_to_reference(got, ref32, ref64, what, tol=RTOL):
 @pytest.mark.parametrize("depth", [5, 4, 6, 3, 2])
 def test_model_golden(pn2, depth):
     """Whole forward + loss + backward of PointNet2 against the imported reference: same FPS starts (same RNG
-    stream), per-point offsets within 1e-4 relative, losses to 1e-4, parameter gradient norms to 5e-4."""
+    stream), per-point offsets within 1e-4 relative, losses to 1e-4.
+
+    Parameter-gradient NORMS are compared with the reference's float64-layer-arithmetic values.  The bar per parameter is
+    max(5e-4, 2 x fixture noise, 3 x this parameter's own |ref32 - ref64| / ref64) x norm + 1e-6 x (largest norm), where
+    "fixture noise" is the largest relative distance between the reference's OWN fp32 norms and their float64 values
+    (~5e-3 at depth 4): gradients of these chains are that ill-conditioned in fp32 for the reference as much as for us,
+    so the effective bar is ~1 % of a norm, not 5e-4.  A norm is also a blunt instrument -- element-wise noise of 6e-3
+    (measured for sa2.mlp_bns.2.bias at depth 3, tests/golden/model_d3_bn_grads.npz) moves a 128-element norm by
+    anything up to a few percent depending on how it correlates with the gradient -- which is why the contested
+    parameters are additionally compared element by element (tests/test_round2.py::test_depth3_bn_gradients_elementwise)
+    and why the selected `g__*` tensors below are."""
     from pn2_amd.PointNet2.PointNet2 import PointNet2
     g = gold(f"model_d{depth}.npz")
     model = seeded_model(PointNet2, g, depth).cuda().train()
@@ -385,7 +395,7 @@ def test_model_golden(pn2, depth):
             wn = float(params[name[:-4] + "weight"].grad.double().norm())
             assert got <= 1e-2 * wn, f"{name}: pre-BN bias gradient should vanish, got {got} (weight grad {wn})"
         else:
-            bar = max(5e-4, 2 * noise) * l2_64 + 5e-6 * gmax
+            bar = max(5e-4 * l2_64, 2 * noise * l2_64, 3 * abs(l2 - l2_64)) + 1e-6 * gmax
             assert abs(got - l2_64) <= bar, f"grad norm of {name}: hip {got}, ref32 {l2}, ref f64 {l2_64}"
     for key in g.files:
         if key.startswith("g__") and not helpers.is_pre_bn_bias(key[3:]):
@@ -497,7 +507,8 @@ def test_forward_hierarchical_streaming_golden(pn2):
         if helpers.is_pre_bn_bias(name):
             continue
         got = float(params[name].grad.double().norm())
-        assert abs(got - l64) <= max(5e-4, 2 * noise) * l64 + 5e-6 * gmax, f"accumulated grad norm of {name}: {got} vs {l64}"
+        bar = max(5e-4 * l64, 2 * noise * l64, 3 * abs(l2 - l64)) + 1e-6 * gmax
+        assert abs(got - l64) <= bar, f"accumulated grad norm of {name}: {got} vs {l64}"
 
     batch["mini_batches"] = mini_batches()
     torch.manual_seed(32)

@@ -8,7 +8,7 @@ from pn2_amd.synthetic import gaussian_branch_tree
 lib = ctypes.CDLL(os.path.join(PKG_DIR, "build_diag", "libpn2hip_diag.so"))
 lib.pn2_fps_workspace_bytes.restype = ctypes.c_size_t
 vp, i64 = ctypes.c_void_p, ctypes.c_int64
-lib.pn2_fps_f32.argtypes = [vp, i64, i64, i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, ctypes.c_size_t, vp]
+lib.pn2_fps_f32.argtypes = [vp, i64, i64, i64, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, ctypes.c_size_t, vp, vp]
 for (N, npoint, B) in [(262144, 1024, 1), (65536, 1024, 8), (1024, 256, 1)]:
     xyz = np.stack([gaussian_branch_tree(N, seed=s)[0] for s in range(B)])
     x = torch.from_numpy(xyz.transpose(0, 2, 1).copy()).cuda()        # [B,3,N]
@@ -18,7 +18,7 @@ for (N, npoint, B) in [(262144, 1024, 1), (65536, 1024, 8), (1024, 256, 1)]:
     ws = torch.zeros(nb, dtype=torch.uint8, device="cuda")
     for _ in range(3):
         st = lib.pn2_fps_f32(x.data_ptr(), x.stride(0), x.stride(2), x.stride(1), B, N, npoint, start.data_ptr(), idx.data_ptr(), None,
-                             ws.data_ptr(), nb, torch.cuda.current_stream().cuda_stream)
+                             ws.data_ptr(), nb, None, torch.cuda.current_stream().cuda_stream)
         assert st == 0
         torch.cuda.synchronize()
     xcd = 8192 < N <= 524288
