@@ -153,7 +153,7 @@ def test_fps_timeout_is_loud(pn2, mode, N, npoint):
     assert word & 3, "no FPS failure bit in the status word"
     i = idx.cpu().numpy()
     assert (i == -1).any() and i[0, 0] in (5, -1)
-    assert np.isnan(new_xyz.cpu().numpy()[i[0] == -1]).all()
+    assert np.isnan(new_xyz.cpu().numpy()[0][i[0] == -1]).all()
     with pytest.raises(RuntimeError, match="farthest_point_sample"):
         ops.check_status()
     # downstream: the -1 rows are not followed, and flagged
@@ -374,10 +374,11 @@ def _dp_worker(rank, world, port, n, trees, depth, q):
     (loss * 50).backward()
     sync.allreduce()
     ops.check_status()
+    # numpy, not tensors: torch shares tensor storage through file descriptors that die with this process
     if rank == 0:
-        q.put(([p.detach().cpu() for p in model.parameters()], sync.flat.cpu(), float(loss)))
+        q.put(([p.detach().cpu().numpy() for p in model.parameters()], sync.flat.cpu().numpy(), float(loss)))
     else:
-        q.put((None, sync.flat.cpu(), float(loss)))
+        q.put((None, sync.flat.cpu().numpy(), float(loss)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -401,8 +402,8 @@ def test_two_rank_gradient_equals_sequential_emulation(pn2, n, trees, depth):
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    params0 = next(r[0] for r in res if r[0] is not None)
-    flats = [r[1] for r in res]
+    params0 = [torch.from_numpy(a) for a in next(r[0] for r in res if r[0] is not None)]
+    flats = [torch.from_numpy(r[1]) for r in res]
     assert torch.equal(flats[0], flats[1]), "ranks disagree after the all-reduce"
     # sequential emulation with rank 0's initial weights
     _, batch = _tree_batch(n, seed=20, trees=trees)
