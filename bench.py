@@ -1,14 +1,20 @@
 """Headline benchmark: points/sec of PointNet2 forward + loss + backward on a synthetic 262 144-point tree.
 
-    python bench.py [--gpus N --steps K --warmup W] [--depth 4|5] [--points 262144]
+    python bench.py [--gpus N --steps K --warmup W] [--mode monolithic|rasterized] [--depth D] [--points P] [--dtype f32]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A step = zero grads, PointNet2.forward (SA x4, FP x4, heads), offset-regression loss, backward of 50*loss, one
-gradient all-reduce (N > 1) and the AdamW update -- one pass of the hot path over one batch (one tree per rank:
-weak scaling, no data-path collective).  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE
-JSON line: the contract fields plus `roofline` (dominant libpn2hip kernel at its dominant launch shape, HIP-event timed
-on its launch stream during a second, instrumented run of the same steps) and `cpu_baseline` (oracle/torch_port.py, the torch-CPU
-restatement of the reference path, timed on this box's host cores; rank 0, N = 1 only).
+--mode monolithic (default; BASELINE configs[1]): a step = zero grads, PointNet2.forward on the whole tree as ONE cloud
+  (depth 4: the training script's layer table), offset-regression loss, backward of 50*loss, one gradient all-reduce
+  (N > 1) and the AdamW update.
+--mode rasterized (what train_PointNet2.py --hierarchical --streaming does): the same tree cut
+  into 1 m rasters, mini-batches of 10 rasters zero-padded to the group maximum, depth 5,
+  PointNet2.forward_hierarchical_streaming with a backward per mini-batch (accumulated), ONE optimizer step per tree.
+
+One pass of the hot path over one batch per step; one tree per rank (weak scaling, no data-path collective).  Inputs are
+resident in HBM before the timed region.  Rank 0 prints ONE JSON line: the contract fields plus `roofline` (the dominant
+libpn2hip kernel at its dominant launch shape, HIP-event timed on its launch stream during a second, instrumented run of the
+same steps) and `cpu_baseline` (oracle/torch_port.py, the torch-CPU restatement of the reference path, timed on this
+box's host cores; rank 0, N = 1 only).
 """
 import argparse
 import json
@@ -27,23 +33,30 @@ PMC_NAMES = {"fps": "fps_multi_kernel", "gemm_fwd": "gemm_kernel<true, 1, true, 
              "gemm_wgrad": "gemm_kernel<false, 2, false, 1, 2, 128", "three_interpolate_grad": "tig_reduce_kernel",
              "ball_query": "ball_query_kernel", "three_nn": "three_nn_kernel", "narrow_bwd": "narrow_bwd_kernel",
              "narrow_fwd": "narrow_fwd_kernel"}
-PMC_FILE = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
+PMC_FILES = [os.path.join(REPO, "profiles", f) for f in ("r02_pmc_traffic.json", "r01_pmc_traffic.json")]
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
-    command (separate passes, gfx950 corrections as in tools/pmc_traffic.py); None when not collected."""
-    try:
-        table = json.load(open(PMC_FILE))
-    except Exception:
-        return None
+    """(HBM bytes per launch of `kernel`, source file) from the committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
+    this command (separate passes, gfx950 corrections as in tools/pmc_traffic.py).  NOT measured in this run: PMC
+    collection needs its own rocprofv3 passes; the source is named in the JSON line so a stale figure is visible."""
     key = PMC_NAMES.get(kernel)
-    rows = [v for k, v in table.items() if key and key in k]
-    return max(r["traffic_bytes_per_launch"] for r in rows) if rows else None
+    for path in PMC_FILES:
+        try:
+            table = json.load(open(path))
+        except Exception:
+            continue
+        rows = [v for k, v in table.items() if key and key in k]
+        if rows:
+            return max(r["traffic_bytes_per_launch"] for r in rows), os.path.relpath(path, REPO)
+    return None, None
 
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
-F32_MFMA_PEAK_TFLOPS = 157.3   # dense fp32-input MFMA peak
+F32_MFMA_PEAK_TFLOPS = 157.3   # dense fp32-input MFMA peak (v_mfma_f32_32x32x2_f32)
+F32_VALU_PEAK_TFLOPS = 157.3   # fp32 vector peak (same 64 FLOP/clk/SIMD rate): the ceiling of the distance-scan kernels
+MFMA_KERNELS = ("gemm", "narrow")
+METRIC = "points/sec fwd+bwd, PointNet2 offset-regression, 262k-pt tree, 1/2/4/8 GPUs"
 
 
 def make_batch(n_points, seed, device, trees=1):
@@ -62,6 +75,34 @@ def make_batch(n_points, seed, device, trees=1):
         "semantic_labels": torch.zeros(total, dtype=torch.long, device=device),
         "offset_labels": torch.from_numpy(off).to(device),
     }
+
+
+def make_raster_stream(n_points, seed, device, mbs=10):
+    """The tree as the reference's streaming collate hands it over (RasterizedTreeSet.py:390-459): 1 m rasters
+    (size = stride = 1.0), mini-batches of `mbs` rasters zero-padded to the group's longest, raw metres, dummy features
+    (zero on padding).  -> (list of mini-batch dicts on `device`, label dict, padded point count)."""
+    import numpy as np
+    from pn2_amd.synthetic import gaussian_branch_tree, rasterize
+    xyz, off, _ = gaussian_branch_tree(n_points, seed=seed)
+    rasters = rasterize(xyz, 1.0, 1.0)
+    out, padded = [], 0
+    for k in range(0, len(rasters), mbs):
+        group = rasters[k:k + mbs]
+        nmax = max(len(r) for r in group)
+        coords = np.zeros((len(group), 3, nmax), np.float32)
+        mpad = np.zeros((len(group), nmax), bool)
+        for i, r in enumerate(group):
+            coords[i, :, :len(r)] = xyz[r].T
+            mpad[i, :len(r)] = True
+        ids = np.concatenate(group)
+        pad_t = torch.from_numpy(mpad).to(device)
+        out.append({"coords": torch.from_numpy(coords).to(device), "feats": torch.ones(len(group), 4, nmax, device=device) * pad_t[:, None, :],
+                    "masks_pad": pad_t, "masks_off": torch.ones(len(ids), dtype=torch.bool, device=device),
+                    "point_ids": torch.from_numpy(ids).to(device)})
+        padded += len(group) * nmax
+    labels = {"cloud_length": n_points, "semantic_labels": torch.zeros(n_points, 1, dtype=torch.long, device=device),
+              "offset_labels": torch.from_numpy(off).to(device)}
+    return out, labels, padded, len(rasters)
 
 
 def host_cores():
@@ -101,19 +142,50 @@ def cpu_baseline(depth, n_points, seed, trees=1):
                       f"tree(s), torch CPU fp32, {times[0]:.2f} s and {times[1]:.2f} s"}
 
 
+def cpu_baseline_rasterized(depth, n_points, seed):
+    """The reference's streaming loop (PointNet2.py:238-306) restated on the CPU port: per mini-batch forward, offset loss
+    on the real points, backward of 50*loss (accumulated), one AdamW step per tree.  One whole tree = the bounded sample."""
+    from oracle import torch_port as P
+    torch.set_num_threads(host_cores())
+    stream, labels, padded, n_rasters = make_raster_stream(n_points, seed, "cpu")
+    torch.manual_seed(0)
+    model = P.PortPointNet2(depth=depth).train()
+    opt = torch.optim.AdamW(model.parameters(), lr=0.01, weight_decay=1e-3)
+    t0 = time.perf_counter()
+    opt.zero_grad()
+    for mb in stream:
+        sem, off = model(mb["coords"], mb["feats"])
+        keep = mb["masks_pad"].reshape(-1)
+        off_v = off.permute(0, 2, 1).reshape(-1, 3)[keep][mb["masks_off"]]
+        lab = labels["offset_labels"][mb["point_ids"]][mb["masks_off"]]
+        _, lo = P.point_wise_loss(sem.permute(0, 2, 1).reshape(-1, 2)[keep], off_v, labels["semantic_labels"].squeeze()[mb["point_ids"]], lab)
+        (lo * 50).backward()
+    opt.step()
+    dt = time.perf_counter() - t0
+    return {"value": n_points / dt, "unit": "points/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"one whole tree in the reference's streaming loop: {len(stream)} mini-batches of 10 rasters "
+                      f"({n_rasters} rasters, {padded} padded points), depth {depth}, fwd + offset loss + bwd per mini-batch, "
+                      f"one AdamW step, torch CPU fp32, {dt:.2f} s"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--depth", type=int, default=4, help="reference layer table (train_PointNet2.py default: 4)")
+    ap.add_argument("--mode", choices=["monolithic", "rasterized"], default="monolithic")
+    ap.add_argument("--depth", type=int, default=None, help="reference layer table (default: 4 monolithic = train_PointNet2.py's, "
+                                                            "5 rasterized = the shipping table)")
     ap.add_argument("--points", type=int, default=262144)
-    ap.add_argument("--trees", type=int, default=1, help="trees per GPU per step (BASELINE configs[2]: 8 x 65536)")
+    ap.add_argument("--trees", type=int, default=1, help="monolithic: trees per GPU per step (BASELINE configs[2]: 8 x 65536)")
+    ap.add_argument("--dtype", choices=["f32"], default="f32", help="arithmetic of the path (fp32 = the reference's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    rasterized = args.mode == "rasterized"
+    depth = args.depth if args.depth is not None else (5 if rasterized else 4)
 
     load_pkg()
-    from pn2_amd import _hip, parallel
+    from pn2_amd import _hip, ops, parallel
     from pn2_amd.PointNet2.PointNet2 import PointNet2
 
     rank, local, world = parallel.init_from_env()
@@ -125,16 +197,26 @@ def main():
     dev = torch.device("cuda", local)
 
     torch.manual_seed(0)                                  # identical random-init weights on every rank
-    model = PointNet2(depth=args.depth, loss_multiplier_semantic=0).to(dev).train()
+    model = PointNet2(depth=depth, loss_multiplier_semantic=0).to(dev).train()
     grads = parallel.FlatGradAllReduce(model)
     opt = torch.optim.AdamW(model.parameters(), lr=0.01, weight_decay=1e-3, fused=True)   # train_PointNet2.py:250
-    batch = make_batch(args.points, seed=rank, device=dev, trees=args.trees)
+    if rasterized:
+        stream, labels, padded, n_rasters = make_raster_stream(args.points, seed=rank, device=dev)
+    else:
+        batch = make_batch(args.points, seed=rank, device=dev, trees=args.trees)
     torch.manual_seed(1000 + rank)                        # FPS start indices: per-rank stream
+
+    class Scaler:                                         # fp32: the reference's GradScaler would scale by 1
+        def scale(self, x):
+            return x
 
     def step():
         grads.zero()
-        loss, _ = model(batch, return_loss=True)
-        (loss * 50).backward()                            # train_utils.py:57-58
+        if rasterized:
+            loss, _ = model.forward_hierarchical_streaming(dict(labels, mini_batches=iter(stream)), return_loss=True, scaler=Scaler())
+        else:
+            loss, _ = model(batch, return_loss=True)
+            (loss * 50).backward()                        # train_utils.py:57-58
         grads.allreduce()
         opt.step()
         return loss
@@ -156,7 +238,8 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
-    assert torch.isfinite(loss).item()
+    ops.check_status()                                    # no kernel gave up during the timed steps
+    assert (loss == loss) if isinstance(loss, float) else torch.isfinite(loss).item()
 
     # second, instrumented run of the same steps: the library brackets every kernel launch with HIP events on its
     # launch stream (pn2_prof_enable) and aggregates per (kernel, launch shape)
@@ -176,8 +259,8 @@ def main():
             k["ms_per_step"] += gr["ms"] / args.steps
         for k in kernels.values():
             k["share_of_step"] = k["ms_per_step"] / step_ms
-        # every library kernel at its heaviest launch shape against both ceilings ("valu" for the distance scans, whose
-        # work is fp32 vector math on the same 157 TFLOP/s peak; "mfma" for the GEMMs)
+        # every library kernel at its heaviest launch shape against both ceilings: "mfma" (fp32 matrix peak) for the
+        # contractions, "valu" (fp32 vector peak) for the distance scans
         per_kernel = {}
         for gr in groups:
             cur = per_kernel.get(gr["name"])
@@ -189,39 +272,56 @@ def main():
             row = {"avg_launch_us": 1e6 * t, "launches_per_step": gr["calls"] / args.steps,
                    "hbm_GBs": gr["bytes"] / t / 1e9, "hbm_frac": gr["bytes"] / t / 1e9 / HBM_PEAK_GBS}
             if gr["flops"] > 0:
+                mfma = name.startswith(MFMA_KERNELS)
                 row["TFLOPs"] = gr["flops"] / t / 1e12
-                row["compute_frac"] = row["TFLOPs"] / F32_MFMA_PEAK_TFLOPS
-                row["compute_unit"] = "mfma" if name.startswith(("gemm", "narrow")) else "valu"
+                row["compute_unit"] = "mfma" if mfma else "valu"
+                row["compute_frac"] = row["TFLOPs"] / (F32_MFMA_PEAK_TFLOPS if mfma else F32_VALU_PEAK_TFLOPS)
             rooflines[name] = row
         dom = max(groups, key=lambda gr: gr["ms"])            # dominant (kernel, shape) by total time
         avg_s = dom["ms"] / dom["calls"] * 1e-3
         hbm = dom["bytes"] / avg_s / 1e9
         tfl = dom["flops"] / avg_s / 1e12
-        if dom["name"].startswith(("gemm", "narrow")) and tfl / F32_MFMA_PEAK_TFLOPS > hbm / HBM_PEAK_GBS:
+        if dom["name"].startswith(MFMA_KERNELS) and tfl / F32_MFMA_PEAK_TFLOPS > hbm / HBM_PEAK_GBS:
             roofline = {"kernel": dom["name"], "bound": "mfma", "achieved": tfl, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": tfl / F32_MFMA_PEAK_TFLOPS, "traffic": None, "hbm_GBs": hbm, "hbm_frac": hbm / HBM_PEAK_GBS}
         else:
             roofline = {"kernel": dom["name"], "bound": "hbm", "achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": hbm / HBM_PEAK_GBS, "traffic": None}
-        roofline["traffic"] = pmc_traffic(dom["name"])
+        if dom["name"] == "fps":
+            # FPS is npoint strictly dependent argmax rounds over data that stays in registers: the ceiling is the
+            # latency of a round, not HBM; the figure to drive down is microseconds per sample
+            npoint = {4: 1024, 3: 1024, 2: 1024, 5: 100, 6: 500}.get(depth, 1024)
+            roofline.update({"bound": "latency", "us_per_sample": 1e6 * avg_s / npoint, "samples": npoint,
+                             "note": "hbm figures kept for the contract; the kernel reads its cloud once and is bound by dependent rounds"})
+        traffic, source = pmc_traffic(dom["name"])
+        roofline["traffic"] = traffic
+        roofline["traffic_source"] = (f"{source}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; "
+                                      "not re-measured in this run") if source else None
         roofline.update({"algorithmic_bytes_per_launch": dom["bytes"], "algorithmic_flops_per_launch": dom["flops"],
                          "avg_launch_us": 1e6 * avg_s, "launches_per_step": dom["calls"] / args.steps,
                          "share_of_step": dom["ms"] / args.steps / step_ms})
+        if rasterized:
+            workload = (f"PointNet2 depth {depth} fwd+loss+bwd+AdamW, the reference's streaming raster mode: one {args.points}-point "
+                        f"Gaussian-branch tree per GPU as {n_rasters} one-metre rasters in {len(stream)} mini-batches of 10 "
+                        f"({padded} padded points), backward per mini-batch, one optimizer step per tree (SURVEY 8d config 2(i)), "
+                        f"fp32 parity mode")
+        else:
+            workload = (f"PointNet2 depth {depth} fwd+loss+bwd+AdamW, B={args.trees} x {args.points}-point Gaussian-branch tree(s) per "
+                        f"GPU ({'BASELINE configs[1], monolithic' if args.trees == 1 else 'BASELINE configs[2] shape'}), fp32 parity mode")
         out = {
-            "metric": "points/sec fwd+bwd, PointNet2 offset-regression, 262k-pt tree, 1/2/4/8 GPUs",
+            "metric": METRIC,
             "value": args.points * args.trees * world * args.steps / dt, "unit": "points/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"PointNet2 depth {args.depth} fwd+loss+bwd+AdamW, B={args.trees} x {args.points}-point "
-                                   f"Gaussian-branch tree(s) per GPU "
-                                   f"({'BASELINE configs[1], monolithic' if args.trees == 1 else 'BASELINE configs[2] shape'}), "
-                                   f"fp32 parity mode",
-                       "points_per_gpu": args.points * args.trees, "trees_per_gpu": args.trees, "depth": args.depth,
+            "config": {"workload": workload, "mode": args.mode, "points_per_gpu": args.points * args.trees,
+                       "trees_per_gpu": args.trees, "depth": depth,
                        "parallelism": f"dp{world} ({args.trees} tree(s) per rank, 1 flat gradient all-reduce per step)"},
             "roofline": roofline, "kernels": kernels, "rooflines": rooflines,
+            "library_launches_per_step": sum(k["launches_per_step"] for k in kernels.values()),
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.depth, args.points, seed=0, trees=args.trees)
+            out["cpu_baseline"] = (cpu_baseline_rasterized(depth, args.points, seed=0) if rasterized
+                                   else cpu_baseline(depth, args.points, seed=0, trees=args.trees))
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     if world > 1:

@@ -79,10 +79,11 @@ class MLP(nn.Sequential):
         nn.init.constant_(self[-1].bias, 0)
 
 
-def _group_mlp_max(grouped, convs, bns):
-    """grouped [B,S,K,C] -> per-group MLP and max over K -> [B,S,C_out] (reference blocks.py:93-98)."""
+def _group_mlp_max(grouped, convs, bns, seg_off=None):
+    """grouped [B,S,K,C] -> per-group MLP and max over K -> [B,S,C_out] (reference blocks.py:93-98).
+    seg_off: row offsets of the mini-batches the B clouds belong to (whole-tree execution, streaming.py)."""
     B, S, K, C = grouped.shape
-    y = chain_rows(grouped.reshape(B * S * K, C), [(c, b, True) for c, b in zip(convs, bns)], pool_k=K)
+    y = chain_rows(grouped.reshape(B * S * K, C), [(c, b, True) for c, b in zip(convs, bns)], pool_k=K, seg_off=seg_off)
     return y.view(B, S, -1)
 
 

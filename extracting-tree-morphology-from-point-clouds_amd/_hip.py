@@ -29,6 +29,24 @@ class MLPLayer(ctypes.Structure):
 
 _lp = ctypes.POINTER(MLPLayer)
 
+
+class Segments(ctypes.Structure):
+    """struct pn2_segments of include/pn2_hip.h: row_off is a HOST int32 array of nseg + 1 offsets."""
+    _fields_ = [("nseg", ctypes.c_int32), ("row_off", ctypes.POINTER(ctypes.c_int32))]
+
+
+_sp = ctypes.POINTER(Segments)
+MAX_SEGMENTS = 128                   # PN2_MAX_SEGMENTS
+
+
+def segments_arg(row_off):
+    """row_off: sequence of nseg + 1 ascending ints (or None) -> (ctypes pointer or None, keep-alive object)."""
+    if row_off is None or len(row_off) <= 2:
+        return None, None
+    arr = (ctypes.c_int32 * len(row_off))(*[int(v) for v in row_off])
+    seg = Segments(len(row_off) - 1, ctypes.cast(arr, ctypes.POINTER(ctypes.c_int32)))
+    return ctypes.pointer(seg), (arr, seg)
+
 # name -> (restype, argtypes); must list every symbol include/pn2_hip.h declares (tests/test_abi.py checks)
 SIGNATURES = {
     "pn2_version": (_int, []),
@@ -58,9 +76,19 @@ SIGNATURES = {
     "pn2_prof_enable": (None, [_int]),
     "pn2_prof_collect": (_int, [ctypes.c_char_p, _sz, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong),
                                 ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _int]),
-    "pn2_mlp_workspace_bytes": (_sz, [_int, _lp, _int]),
-    "pn2_mlp_chain_fwd_f32": (_int, [_vp, _i64, _int, _lp, _int, _int, _int, _vp, _vp, _vp, _sz, _vp]),
-    "pn2_mlp_chain_bwd_f32": (_int, [_vp, _i64, _int, _lp, _int, _int, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "pn2_mlp_workspace_bytes": (_sz, [_int, _lp, _int, _int]),
+    "pn2_mlp_chain_fwd_f32": (_int, [_vp, _i64, _int, _lp, _int, _int, _int, _vp, _vp, _sp, _vp, _sz, _vp]),
+    "pn2_mlp_chain_bwd_f32": (_int, [_vp, _i64, _int, _lp, _int, _int, _vp, _vp, _vp, _i64, _vp, _vp, _sp, _vp, _sz, _vp]),
+    "pn2_fps_ragged_workspace_bytes": (_sz, [_int, _int, _int]),
+    "pn2_fps_ragged_f32": (_int, [_vp, _vp, _int, _int, _int, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "pn2_ball_query_ragged_f32": (_int, [_vp, _vp, _vp, _int, _int, _int, _f32, _int, _vp, _vp]),
+    "pn2_group_ragged_f32": (_int, [_vp, _vp, _int, _vp, _vp, _vp, _int, _int, _int, _int, _vp, _vp, _vp]),
+    "pn2_three_nn_ragged_f32": (_int, [_vp, _vp, _vp, _int, _int, _int, _vp, _vp, _vp]),
+    "pn2_three_interpolate_ragged_f32": (_int, [_vp, _vp, _vp, _vp, _int, _int, ctypes.c_longlong, _int, _int, _vp, _i64, _i64,
+                                                _vp, _vp]),
+    "pn2_three_interpolate_grad_ragged_workspace_bytes": (_sz, [_int, ctypes.c_longlong, _int]),
+    "pn2_three_interpolate_grad_ragged_f32": (_int, [_vp, _i64, _i64, _vp, _vp, _vp, _int, _int, ctypes.c_longlong, _int, _int,
+                                                     _vp, _vp, _sz, _vp]),
 }
 
 _lib = None

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(kBlock) void ball_query_kernel(const float* __restr
                                                             int64_t qs, int64_t qc, int B, int N, int S, float r2,
                                                             int Keff, int32_t* __restrict__ out_idx, int seg_len,
                                                             int nseg, int32_t* __restrict__ part_idx,
-                                                            int32_t* __restrict__ part_cnt) {
+                                                            int32_t* __restrict__ part_cnt, const int* __restrict__ coff) {
     const int lane = threadIdx.x & 63;
     const int nqg = (S + Q - 1) / Q;
     // wave order [b][seg][query group]: the 4 waves of a workgroup scan the same segment
@@ -83,7 +83,9 @@ __global__ __launch_bounds__(kBlock) void ball_query_kernel(const float* __restr
     const int seg = (int)((w / nqg) % nseg);
     const int b = (int)(w / ((long long)nqg * nseg));
 
-    const Cloud c{xyz + (int64_t)b * sb, sn, sc};
+    const pn2::CloudView cv = pn2::cloud_view(xyz, sb, sn, sc, N, coff, b, 3);   // ragged batches: nseg == 1
+    const Cloud c{cv.p, cv.sn, cv.sc};
+    N = cv.n;
     static_assert(Q % 2 == 0, "queries are tested in pairs");
     float qx[Q], qy[Q], qz[Q], qn[Q];
     int cnt[Q], first[Q];
@@ -276,7 +278,7 @@ extern "C" int pn2_ball_query_f32(const float* xyz, int64_t sb, int64_t sn, int6
 #define PN2_BQ_CASE(Q_)                                                                                               \
     if (p.Q == Q_)                                                                                                    \
         PN2_LAUNCH("ball_query", bq_bytes, 8.0 * B * (double)S * N, (ball_query_kernel<Q_>), grid, block, s, xyz, sb, sn, sc, new_xyz, qb, qn, \
-                   qc, B, N, S, r2, Keff, out_idx, p.seg_len, p.nseg, part_idx, part_cnt);
+                   qc, B, N, S, r2, Keff, out_idx, p.seg_len, p.nseg, part_idx, part_cnt, (const int*)nullptr);
     PN2_BQ_CASE(2)
     PN2_BQ_CASE(4)
     PN2_BQ_CASE(8)
@@ -288,5 +290,32 @@ extern "C" int pn2_ball_query_f32(const float* xyz, int64_t sb, int64_t sn, int6
                    s, xyz, sb, sn, sc, new_xyz, qb, qn, qc, B, N, S, Keff, out_idx, p.nseg, part_idx, part_cnt);
         PN2_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+// Ragged batch (whole-tree execution): C small clouds of n_b >= nsample points each, S queries per cloud.  Thousands of
+// (cloud, query group) wavefronts exist already, so every wavefront scans its whole cloud (one segment, no merge pass).
+extern "C" int pn2_ball_query_ragged_f32(const float* xyz_cf, const int32_t* coff, const float* new_xyz, int C, int n_max, int S,
+                                         float r2, int nsample, int32_t* out_idx, void* stream) {
+    if (!xyz_cf || !coff || !new_xyz || !out_idx || C <= 0 || n_max <= 0 || S <= 0 || nsample <= 0) return PN2_E_BADARG;
+    int Q = 8;
+    while (Q > 2 && (long long)C * S < 8 * Q) Q >>= 1;
+    const int nqg = pn2::ceil_div(S, Q);
+    const long long waves = (long long)C * nqg;
+    if (waves > 0x7FFFFFFFll) return PN2_E_BADARG;
+    const dim3 grid((unsigned)((waves + 3) / 4)), block(kBlock);
+    hipStream_t s = (hipStream_t)stream;
+    const double bq_bytes = (double)C * (12.0 * n_max + 12.0 * S + 8.0 * S * nsample);
+    const int seg_len = pn2::ceil_div(n_max, 64) * 64;
+#define PN2_BQ_CASE(Q_)                                                                                                  \
+    if (Q == Q_)                                                                                                         \
+        PN2_LAUNCH("ball_query", bq_bytes, 8.0 * C * (double)S * n_max, (ball_query_kernel<Q_>), grid, block, s, xyz_cf, 0, 1, 0, \
+                   new_xyz, (int64_t)S * 3, 3, 1, C, n_max, S, r2, nsample, out_idx, seg_len, 1, (int32_t*)nullptr,        \
+                   (int32_t*)nullptr, (const int*)coff);
+    PN2_BQ_CASE(2)
+    PN2_BQ_CASE(4)
+    PN2_BQ_CASE(8)
+#undef PN2_BQ_CASE
+    PN2_LAUNCH_CHECK();
     return 0;
 }

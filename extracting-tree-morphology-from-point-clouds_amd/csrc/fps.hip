@@ -72,7 +72,7 @@ template <int PPT, int T>
 __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, int64_t sb, int64_t sn, int64_t sc,
                                                 int B, int N, int npoint, const int64_t* __restrict__ start,
                                                 int32_t* __restrict__ out_idx, float* __restrict__ out_xyz,
-                                                u64* gran, unsigned* err, int G, int groups, Knobs kn) {
+                                                u64* gran, unsigned* err, int G, int groups, Knobs kn, const int* coff) {
     constexpr int NW = T / 64;
     __shared__ u64 s_key[2][NW];
     __shared__ float s_xyz[2][NW][3];
@@ -90,25 +90,26 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
     const int base = g * (T * PPT) + tid;
 
     for (int b = grp; b < B; b += groups) {
-        const float* p = xyz + (int64_t)b * sb;
+        const pn2::CloudView cv = pn2::cloud_view(xyz, sb, sn, sc, N, coff, b, 3);   // ragged batches: G == 1 only
+        const float* p = cv.p;
         float x[PPT], y[PPT], z[PPT], d[PPT];
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
             const int n = base + j * T;
-            const bool ok = n < N;
-            const float* q = p + (int64_t)(ok ? n : 0) * sn;
+            const bool ok = n < cv.n;
+            const float* q = p + (int64_t)(ok ? n : 0) * cv.sn;
             x[j] = q[0];
-            y[j] = q[sc];
-            z[j] = q[2 * sc];
+            y[j] = q[cv.sc];
+            z[j] = q[2 * cv.sc];
             d[j] = ok ? 1e10f : -1.0f;  // -1 marks a slot beyond N: never a maximum, never updated
         }
         int far = (int)start[b];
         float cx, cy, cz;
         {
-            const float* c = p + (int64_t)far * sn;
+            const float* c = p + (int64_t)far * cv.sn;
             cx = c[0];
-            cy = c[sc];
-            cz = c[2 * sc];
+            cy = c[cv.sc];
+            cz = c[2 * cv.sc];
         }
         u64* gb = gran + (size_t)b * npoint * 4 * G;
 
@@ -984,9 +985,10 @@ Config pick(int B, int N) {
 
 template <int PPT, int T>
 void launch(const Config& c, const float* xyz, int64_t sb, int64_t sn, int64_t sc, int B, int N, int npoint,
-            const int64_t* start, int32_t* out_idx, float* out_xyz, u64* gran, unsigned* err, const Knobs& kn, hipStream_t s) {
+            const int64_t* start, int32_t* out_idx, float* out_xyz, u64* gran, unsigned* err, const Knobs& kn, hipStream_t s,
+            const int* coff = nullptr) {
     PN2_LAUNCH("fps", (double)B * (12.0 * N + 8.0 * npoint), 0, (fps_kernel<PPT, T>), dim3(c.groups * c.G), dim3(T), s, xyz, sb,
-               sn, sc, B, N, npoint, start, out_idx, out_xyz, gran, err, c.G, c.groups, kn);
+               sn, sc, B, N, npoint, start, out_idx, out_xyz, gran, err, c.G, c.groups, kn, coff);
 }
 
 Knobs knobs(int32_t* status) {
@@ -1067,6 +1069,47 @@ extern "C" int pn2_fps_f32(const float* xyz, int64_t sb, int64_t sn, int64_t sc,
 #define PN2_FPS_CASE(P, T_)                                                                                  \
     if (c.ppt == P && c.t == T_) {                                                                           \
         launch<P, T_>(c, xyz, sb, sn, sc, B, N, npoint, start, out_idx, out_xyz, gran, err, kn, s);          \
+    } else
+    PN2_FPS_CASE(1, 256)
+    PN2_FPS_CASE(2, 256)
+    PN2_FPS_CASE(4, 256)
+    PN2_FPS_CASE(8, 256)
+    PN2_FPS_CASE(16, 256)
+    PN2_FPS_CASE(4, 1024)
+    PN2_FPS_CASE(8, 1024)
+    PN2_FPS_CASE(16, 512)
+    PN2_FPS_CASE(32, 512) { return PN2_E_BADARG; }
+#undef PN2_FPS_CASE
+    PN2_LAUNCH_CHECK();
+    return 0;
+}
+
+// Ragged batch of small clouds (every cloud <= 16384 points: one workgroup each, no hand-off, nothing to time out).
+// N_max picks the points-per-lane configuration; clouds shorter than that leave lanes idle.
+extern "C" size_t pn2_fps_ragged_workspace_bytes(int C, int n_max, int npoint) {
+    if (C <= 0 || n_max <= 0 || n_max > 32 * 512 || npoint <= 0) return 0;
+    return kHdr;
+}
+
+extern "C" int pn2_fps_ragged_f32(const float* xyz_cf, const int32_t* coff, int C, int n_max, int npoint, const int64_t* start,
+                                  int32_t* out_idx, float* out_xyz, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!xyz_cf || !coff || !start || !out_idx || !workspace || C <= 0 || n_max <= 0 || n_max > 32 * 512 || npoint <= 0)
+        return PN2_E_BADARG;
+    if (workspace_bytes < kHdr) return PN2_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    // one member per cloud: the smallest (points per lane x threads) that covers the longest cloud
+    static const int cand[][2] = {{1, 256}, {2, 256}, {4, 256}, {8, 256}, {16, 256}, {4, 1024}, {8, 1024}, {16, 512}, {32, 512}};
+    Config c{0, 0, 1, C < 256 ? C : 256, 0.0};
+    for (auto& k : cand)
+        if (k[0] * k[1] >= n_max) {
+            if (!c.ppt || 0.02 * k[0] + 0.0004 * k[1] < 0.02 * c.ppt + 0.0004 * c.t) c.ppt = k[0], c.t = k[1];
+        }
+    if (!c.ppt) return PN2_E_BADARG;
+    const Knobs kn = knobs(nullptr);
+    unsigned* err = (unsigned*)workspace;
+#define PN2_FPS_CASE(P, T_)                                                                                              \
+    if (c.ppt == P && c.t == T_) {                                                                                       \
+        launch<P, T_>(c, xyz_cf, 0, 1, 0, C, n_max, npoint, start, out_idx, out_xyz, nullptr, err, kn, s, (const int*)coff); \
     } else
     PN2_FPS_CASE(1, 256)
     PN2_FPS_CASE(2, 256)

@@ -24,21 +24,31 @@ __global__ __launch_bounds__(kBlock) void group_kernel(const float* __restrict__
                                                        const float* __restrict__ new_xyz, const float* __restrict__ feats,
                                                        int64_t fb, int64_t fn, int64_t fc, const int32_t* __restrict__ idx,
                                                        int B, int N, int S, int K, int D, int xyz_last,
-                                                       float* __restrict__ out, long long total, int32_t* status) {
+                                                       float* __restrict__ out, long long total, int32_t* status,
+                                                       const int* __restrict__ coff) {
     const int C = 3 + D;
     for (long long e = (long long)blockIdx.x * kBlock + threadIdx.x; e < total; e += (long long)gridDim.x * kBlock) {
         const long long r = e / C;  // (b, s, k)
         const int c = (int)(e - r * C);
         const long long bs = r / K;
         const int b = (int)(bs / S);
-        const int j = checked(idx[r], N, status);
         const int cx = xyz_last ? c - D : c;  // coordinate channel if in [0,3)
         float v;
-        if (cx >= 0 && cx < 3) {
-            v = __fsub_rn(xyz[(int64_t)b * sb + (int64_t)j * sn + cx * sc], new_xyz[bs * 3 + cx]);
+        if (coff) {  // ragged batch: both tensors channel-first per cloud (pn2_common.h: CloudView)
+            const int o = coff[b], n = coff[b + 1] - o;
+            const int j = checked(idx[r], n, status);
+            if (cx >= 0 && cx < 3)
+                v = __fsub_rn(xyz[3LL * o + (int64_t)cx * n + j], new_xyz[bs * 3 + cx]);
+            else
+                v = feats[(int64_t)D * o + (int64_t)(xyz_last ? c : c - 3) * n + j];
         } else {
-            const int cf = xyz_last ? c : c - 3;
-            v = feats[(int64_t)b * fb + (int64_t)j * fn + cf * fc];
+            const int j = checked(idx[r], N, status);
+            if (cx >= 0 && cx < 3) {
+                v = __fsub_rn(xyz[(int64_t)b * sb + (int64_t)j * sn + cx * sc], new_xyz[bs * 3 + cx]);
+            } else {
+                const int cf = xyz_last ? c : c - 3;
+                v = feats[(int64_t)b * fb + (int64_t)j * fn + cf * fc];
+            }
         }
         out[e] = v;
     }
@@ -97,7 +107,21 @@ extern "C" int pn2_group_f32(const float* xyz, int64_t sb, int64_t sn, int64_t s
         return PN2_E_BADARG;
     const long long total = (long long)B * S * K * (3 + D);
     PN2_LAUNCH("group", 8.0 * total + 4.0 * B * S * K, 0, group_kernel, dim3(grid_for(total)), dim3(kBlock), (hipStream_t)stream,
-               xyz, sb, sn, sc, new_xyz, feats, fb, fn, fc, idx, B, N, S, K, D, xyz_last, out, total, status);
+               xyz, sb, sn, sc, new_xyz, feats, fb, fn, fc, idx, B, N, S, K, D, xyz_last, out, total, status,
+               (const int*)nullptr);
+    PN2_LAUNCH_CHECK();
+    return 0;
+}
+
+// Ragged batch: xyz_cf / feats_cf are the flat channel-first buffers (3 resp. D planes per cloud), idx is cloud-local.
+extern "C" int pn2_group_ragged_f32(const float* xyz_cf, const float* feats_cf, int D, const int32_t* coff,
+                                    const float* new_xyz, const int32_t* idx, int C, int S, int K, int xyz_last, float* out,
+                                    int32_t* status, void* stream) {
+    if (!xyz_cf || !coff || !new_xyz || !idx || !out || C <= 0 || S <= 0 || K <= 0 || D < 0 || (D > 0 && !feats_cf))
+        return PN2_E_BADARG;
+    const long long total = (long long)C * S * K * (3 + D);
+    PN2_LAUNCH("group", 8.0 * total + 4.0 * C * S * K, 0, group_kernel, dim3(grid_for(total)), dim3(kBlock), (hipStream_t)stream,
+               xyz_cf, 0, 1, 0, new_xyz, feats_cf, 0, 1, 0, idx, C, 0, S, K, D, xyz_last, out, total, status, (const int*)coff);
     PN2_LAUNCH_CHECK();
     return 0;
 }

@@ -35,6 +35,40 @@ enum { EPI_FWD = 0, EPI_STORE = 1, EPI_SLAB = 2 };
 // rows of a layer's coefficient block (each `C` floats): see pn2_mlp_layer.stats in pn2_hip.h
 enum { ST_MEAN = 0, ST_VAR = 1, ST_INVSTD = 2, ST_SCALE = 3, ST_BETA = 4, ST_A = 5, ST_B = 6, ST_ROWS = 8 };
 
+// Row SEGMENTS (whole-tree execution): the rows of a chain are the concatenation of nseg mini-batches, each with its
+// OWN train-mode BatchNorm statistics (the reference runs them as separate forward passes, PointNet2.py:238-306).
+// Every kernel that needs a row's statistics is launched over row BLOCKS that never straddle a segment boundary:
+// block i of a launch covers rows [row_off[s] + (i - blk_off[s]) * R, ...) of the segment s with
+// blk_off[s] <= i < blk_off[s+1] (R = the launch's block size: GEMM tile, reduction block, ...).  The table travels BY
+// VALUE in the kernel arguments (kernarg segment: scalar loads), so there is nothing to build or upload on the device.
+// nseg == 1 is the ordinary batch: block i covers rows [i * R, ...).
+constexpr int kMaxSegs = PN2_MAX_SEGMENTS;
+struct SegTable {
+    int nseg;
+    int row_off[kMaxSegs + 1];
+    int blk_off[kMaxSegs + 1];
+};
+struct RowBlock {
+    int seg, row0, row_end;
+};
+// wave-uniform: blockIdx -> (segment, first row, end of the segment)
+__device__ __forceinline__ RowBlock row_block(const SegTable& st, int blk, int R) {
+    int lo = 0, hi = st.nseg;
+    while (hi - lo > 1) {  // largest s with blk_off[s] <= blk
+        const int mid = (lo + hi) >> 1;
+        if (st.blk_off[mid] <= blk) lo = mid; else hi = mid;
+    }
+    return RowBlock{lo, st.row_off[lo] + (blk - st.blk_off[lo]) * R, st.row_off[lo + 1]};
+}
+__device__ __forceinline__ int seg_of_row(const SegTable& st, int row) {
+    int lo = 0, hi = st.nseg;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (st.row_off[mid] <= row) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
 struct Operand {
     const float* p;   // X, Y or dZ: [rows][cols], cols (= channels) contiguous
     const float* q;   // TR_DY: the layer's pre-BN output Y
@@ -191,7 +225,7 @@ struct GemmArgs {
 // FULL: the wave's sub-tile lies inside the matrix -- no per-element bounds checks (64 predicated stores otherwise)
 template <int EPI, int NI, bool FULL>
 __device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& g, f32x16 (&acc)[NI][NI], int row0, int col0, int chunk_rows,
-                                              int lane, int split) {
+                                              int lane, int split, long long chunk) {
     const int l31 = lane & 31, half = lane >> 5;
     const int m0 = row0, wm = 0, WT = chunk_rows, n0 = col0, wn = 0;   // names used by the body below
     (void)wm; (void)wn;
@@ -220,7 +254,6 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& g, f32x16 (&a
                 }
             }
         // per-(row chunk of WT rows, column) partials; the other half-wave holds the other rows of the column
-        const long long chunk = (m0 + wm * WT) / WT;
         if (EPI == EPI_FWD && g.partial) {
             sum += __shfl_xor(sum, 32, 64);
             cnt += __shfl_xor(cnt, 32, 64);
@@ -270,11 +303,11 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& g, f32x16 (&a
 
 template <int EPI, int NI>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[NI][NI], int row0, int col0, int chunk_rows,
-                                              int lane, int split) {
+                                              int lane, int split, long long chunk) {
     if (row0 + 32 * NI <= g.M && col0 + 32 * NI <= g.N)
-        gemm_epilogue_impl<EPI, NI, true>(g, acc, row0, col0, chunk_rows, lane, split);
+        gemm_epilogue_impl<EPI, NI, true>(g, acc, row0, col0, chunk_rows, lane, split, chunk);
     else
-        gemm_epilogue_impl<EPI, NI, false>(g, acc, row0, col0, chunk_rows, lane, split);
+        gemm_epilogue_impl<EPI, NI, false>(g, acc, row0, col0, chunk_rows, lane, split, chunk);
 }
 
 // TEAMS = 4 (64-tiles only): the block holds four 256-thread teams that each contract a quarter of K into their own
@@ -282,8 +315,29 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[N
 // hundred rows and K up to 768: a handful of workgroups whose serial K loop is pure latency -- four teams put four
 // times the loads in flight and give every SIMD four waves to interleave.
 template <bool A_T, int A_KIND, bool B_T, int B_KIND, int EPI, int TILE, bool VEC, int TEAMS>
-__global__ __launch_bounds__(NT * TEAMS, (TEAMS > 1 ? 1 : (EPI == EPI_STORE ? 2 : 3))) void gemm_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(NT * TEAMS, (TEAMS > 1 ? 1 : (EPI == EPI_STORE ? 2 : 3))) void gemm_kernel(const GemmArgs g0,
+                                                                                                         const SegTable st) {
     constexpr int LD = TILE + 4, WT = TILE / 2, NI = WT / 32;
+    // Which rows does this workgroup own?  Row tiles (forward, dgrad) and reduction ranges (wgrad) never straddle a
+    // segment: the operands' row limit, the output's row limit and the BatchNorm coefficient blocks are those of the
+    // block's segment (st.nseg == 1: the whole matrix, coefficient block 0).
+    GemmArgs g = g0;
+    int m0 = blockIdx.x * TILE, k_begin = 0, k_end = g.K, seg;
+    if (EPI == EPI_SLAB) {
+        const RowBlock rb = row_block(st, (int)blockIdx.z, g.k_per_split);
+        seg = rb.seg;
+        k_begin = rb.row0;
+        k_end = rb.row0 + g.k_per_split < rb.row_end ? rb.row0 + g.k_per_split : rb.row_end;
+        g.A.rows = g.B.rows = k_end;        // direct layout: rows are the contraction index
+    } else {
+        const RowBlock rb = row_block(st, (int)blockIdx.x, TILE);
+        seg = rb.seg;
+        m0 = rb.row0;
+        g.A.rows = g.M = rb.row_end;
+    }
+    if (g.A.coef) g.A.coef += (long long)seg * ST_ROWS * g.A.cstride;
+    if (g.B.coef) g.B.coef += (long long)seg * ST_ROWS * g.B.cstride;
+    if (EPI == EPI_STORE && g.ecoef) g.ecoef += (long long)seg * ST_ROWS * g.N;
     static_assert(TEAMS == 1 || TILE == 64, "teams are for the small-problem tile");
     // one LDS object (it is re-used as the teams' reduction buffer): [team][A|B][buffer][BK * LD]
     __shared__ __attribute__((aligned(16))) float lds[TEAMS * 4 * BK * LD];
@@ -291,12 +345,7 @@ __global__ __launch_bounds__(NT * TEAMS, (TEAMS > 1 ? 1 : (EPI == EPI_STORE ? 2 
     float(*As)[BK * LD] = (float(*)[BK * LD])(lds + (team * 4 + 0) * BK * LD);
     float(*Bs)[BK * LD] = (float(*)[BK * LD])(lds + (team * 4 + 2) * BK * LD);
 
-    const int m0 = blockIdx.x * TILE, n0 = blockIdx.y * TILE;
-    int k_begin = 0, k_end = g.K;
-    if (EPI == EPI_SLAB) {
-        k_begin = blockIdx.z * g.k_per_split;
-        k_end = k_begin + g.k_per_split < g.K ? k_begin + g.k_per_split : g.K;
-    }
+    const int n0 = blockIdx.y * TILE;
     int nk = (k_end - k_begin + BK - 1) / BK;
     if (TEAMS > 1) {  // every team runs the same number of K-tiles (loads beyond K are zero-filled)
         nk = (nk + TEAMS - 1) / TEAMS;
@@ -380,7 +429,8 @@ __global__ __launch_bounds__(NT * TEAMS, (TEAMS > 1 ? 1 : (EPI == EPI_STORE ? 2 
             for (int r = 0; r < 16; ++r) acc[0][0][r] += red[(t * 16 + r) * NT + tid];
     }
 
-    gemm_epilogue<EPI, NI>(g, acc, m0 + wm * WT, n0 + wn * WT, WT, lane, (int)blockIdx.z);
+    gemm_epilogue<EPI, NI>(g, acc, m0 + wm * WT, n0 + wn * WT, WT, lane, (int)blockIdx.z,
+                           (long long)blockIdx.x * (TILE / WT) + wm);
 }
 
 // ------------------------------------------------------------------------------------------- BatchNorm: forward
@@ -441,6 +491,112 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     }
 }
 
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+// rows of statistics chunk k of segment s: blocks of `cpb` chunks of `crows` rows tile the segment from its first row
+__device__ __forceinline__ int chunk_rows_in_seg(const SegTable& st, int s, int k, int cpb, int crows) {
+    const int row0 = st.row_off[s] + (k - st.blk_off[s] * cpb) * crows;
+    const int left = st.row_off[s + 1] - row0;
+    return left < crows ? left : crows;
+}
+
+// Segmented forward finalize: one block per channel, each wavefront takes segments wave, wave + 4, ...: lanes stride over
+// the segment's (mean, M2) chunk partials (Chan's merge in float64, like bn_finalize_kernel), one coefficient block per
+// segment.  The running statistics see the segments in order -- mini-batch after mini-batch, like the reference's
+// sequential forward passes (momentum update per pass).
+__global__ __launch_bounds__(256) void bn_finalize_seg_kernel(const float* __restrict__ partial, const SegTable st, int cpb, int CH,
+                                                              int C, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float* __restrict__ running_mean,
+                                                              float* __restrict__ running_var, float eps, float momentum,
+                                                              float* __restrict__ coef) {
+    __shared__ double s_mean[kMaxSegs], s_var[kMaxSegs];
+    const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float gm = gamma ? gamma[c] : 1.0f, bt = beta ? beta[c] : 0.0f;
+    for (int s = wave; s < st.nseg; s += 4) {
+        const int k0 = st.blk_off[s] * cpb, k1 = st.blk_off[s + 1] * cpb;
+        const double rows = (double)(st.row_off[s + 1] - st.row_off[s]);
+        double acc = 0.0;
+        for (int k = k0 + lane; k < k1; k += 64) {
+            const int n = chunk_rows_in_seg(st, s, k, cpb, CH);
+            if (n > 0) acc += (double)n * (double)partial[((long long)k * 2) * C + c];
+        }
+        const double mean = wave_sum_f64(acc) / rows;
+        acc = 0.0;
+        for (int k = k0 + lane; k < k1; k += 64) {
+            const int n = chunk_rows_in_seg(st, s, k, cpb, CH);
+            if (n > 0) {
+                const double d = (double)partial[((long long)k * 2) * C + c] - mean;
+                acc += (double)partial[((long long)k * 2 + 1) * C + c] + (double)n * d * d;
+            }
+        }
+        const double var = wave_sum_f64(acc) / rows;
+        if (lane == 0) {
+            float* cf = coef + (long long)s * ST_ROWS * C;
+            const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+            cf[ST_MEAN * C + c] = (float)mean;
+            cf[ST_VAR * C + c] = (float)var;
+            cf[ST_INVSTD * C + c] = invstd;
+            cf[ST_SCALE * C + c] = gm * invstd;
+            cf[ST_BETA * C + c] = bt;
+            s_mean[s] = mean;
+            s_var[s] = var;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && running_mean) {
+        float rm = running_mean[c], rv = running_var[c];
+        for (int s = 0; s < st.nseg; ++s) {   // float after every pass, exactly like nn.BatchNorm's buffer update
+            const int rows = st.row_off[s + 1] - st.row_off[s];
+            const double unbiased = rows > 1 ? s_var[s] * (double)rows / (double)(rows - 1) : s_var[s];
+            rm = (float)((1.0 - momentum) * (double)rm + (double)momentum * s_mean[s]);
+            rv = (float)((1.0 - momentum) * (double)rv + (double)momentum * unbiased);
+        }
+        running_mean[c] = rm;
+        running_var[c] = rv;
+    }
+}
+
+// Segmented backward finalize: per segment s1 = sum dzhat, s2 = sum dzhat * xhat over the segment's chunk partials ->
+// the segment's dY coefficients; dgamma / dbeta are the sums over the segments, added in segment order.
+__global__ __launch_bounds__(256) void bn_bwd_finalize_seg_kernel(const float* __restrict__ partial, const SegTable st, int cpb,
+                                                                  int crows, int C, float* __restrict__ coef,
+                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ double s_1[kMaxSegs], s_2[kMaxSegs];
+    const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int s = wave; s < st.nseg; s += 4) {
+        const int k0 = st.blk_off[s] * cpb, k1 = st.blk_off[s + 1] * cpb;
+        double a1 = 0.0, a2 = 0.0;
+        for (int k = k0 + lane; k < k1; k += 64)
+            if (chunk_rows_in_seg(st, s, k, cpb, crows) > 0) {
+                a1 += (double)partial[((long long)k * 2) * C + c];
+                a2 += (double)partial[((long long)k * 2 + 1) * C + c];
+            }
+        a1 = wave_sum_f64(a1);
+        a2 = wave_sum_f64(a2);
+        if (lane == 0) {
+            const double rows = (double)(st.row_off[s + 1] - st.row_off[s]);
+            float* cf = coef + (long long)s * ST_ROWS * C;
+            cf[ST_A * C + c] = (float)(a1 / rows);
+            cf[ST_B * C + c] = (float)((double)cf[ST_INVSTD * C + c] * a2 / rows);
+            s_1[s] = a1;
+            s_2[s] = a2;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t1 = 0.0, t2 = 0.0;
+        for (int s = 0; s < st.nseg; ++s) {
+            t1 += s_1[s];
+            t2 += s_2[s];
+        }
+        if (dbeta) dbeta[c] += (float)t1;
+        if (dgamma) dgamma[c] += (float)t2;
+    }
+}
+
 // eval mode: coefficients from the running statistics
 __global__ void bn_eval_coef_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
                                     const float* __restrict__ running_mean, const float* __restrict__ running_var, float eps,
@@ -456,6 +612,36 @@ __global__ void bn_eval_coef_kernel(int C, const float* __restrict__ gamma, cons
 }
 
 // z = relu((y - mean) * scale + beta), elementwise, 16 B per lane
+// segmented variant: one block per APPLY_R-row block of one segment (its coefficient block)
+constexpr int APPLY_R = 64;
+__global__ __launch_bounds__(256) void bn_relu_apply_seg_kernel(const float* __restrict__ y, const SegTable st, int C,
+                                                                const float* __restrict__ coef, int relu,
+                                                                float* __restrict__ z) {
+    const RowBlock rb = row_block(st, (int)blockIdx.x, APPLY_R);
+    const int r1 = rb.row0 + APPLY_R < rb.row_end ? rb.row0 + APPLY_R : rb.row_end;
+    const float* cf = coef + (long long)rb.seg * ST_ROWS * C;
+    const long long e0 = (long long)rb.row0 * C / 4, e1 = (long long)r1 * C / 4;
+    for (long long e = e0 + threadIdx.x; e < e1; e += 256) {
+        const int c = (int)((e * 4) % C);
+        const float4 v = ((const float4*)y)[e];
+        const float4 mean = *(const float4*)(cf + ST_MEAN * C + c);
+        const float4 sc = *(const float4*)(cf + ST_SCALE * C + c);
+        const float4 bt = *(const float4*)(cf + ST_BETA * C + c);
+        float4 o;
+        o.x = __builtin_fmaf(v.x - mean.x, sc.x, bt.x);
+        o.y = __builtin_fmaf(v.y - mean.y, sc.y, bt.y);
+        o.z = __builtin_fmaf(v.z - mean.z, sc.z, bt.z);
+        o.w = __builtin_fmaf(v.w - mean.w, sc.w, bt.w);
+        if (relu) {
+            o.x = fmaxf(o.x, 0.f);
+            o.y = fmaxf(o.y, 0.f);
+            o.z = fmaxf(o.z, 0.f);
+            o.w = fmaxf(o.w, 0.f);
+        }
+        ((float4*)z)[e] = o;
+    }
+}
+
 __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const float* __restrict__ y, long long total4, int C,
                                                             const float* __restrict__ coef, int relu, float* __restrict__ z) {
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total4; e += (long long)gridDim.x * 256) {
@@ -482,12 +668,15 @@ __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const float* __restr
 // out[g][c] = max_k relu(bn(y[g*K + k][c])), arg = first k attaining it (torch.max(dim) keeps the first maximum)
 __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const float* __restrict__ y, long long groups, int K, int C,
                                                               const float* __restrict__ coef, int relu,
-                                                              float* __restrict__ out, int32_t* __restrict__ arg) {
+                                                              float* __restrict__ out, int32_t* __restrict__ arg,
+                                                              const SegTable st) {
     const long long total = groups * C;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
         const long long gi = e / C;
         const int c = (int)(e - gi * C);
-        const float mean = coef[ST_MEAN * C + c], sc = coef[ST_SCALE * C + c], bt = coef[ST_BETA * C + c];
+        // a group never straddles a segment (segments are whole clouds)
+        const float* cf = st.nseg > 1 ? coef + (long long)seg_of_row(st, (int)(gi * K)) * ST_ROWS * C : coef;
+        const float mean = cf[ST_MEAN * C + c], sc = cf[ST_SCALE * C + c], bt = cf[ST_BETA * C + c];
         const float* p = y + gi * K * C + c;
         float best = -__builtin_inff();
         int bk = 0;
@@ -525,10 +714,12 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dz, long long lddz,
                                                             const float* __restrict__ y, long long ldy, int rows, int C,
                                                             const float* __restrict__ coef, int relu,
-                                                            float* __restrict__ partial) {
+                                                            float* __restrict__ partial, const SegTable st) {
     __shared__ float red[2][256][4];
-    const int r0 = blockIdx.x * RB;
-    const int r1 = r0 + RB < rows ? r0 + RB : rows;
+    const RowBlock rb = row_block(st, (int)blockIdx.x, RB);
+    const int r0 = rb.row0;
+    const int r1 = r0 + RB < rb.row_end ? r0 + RB : rb.row_end;
+    coef += (long long)rb.seg * ST_ROWS * C;
     const int C4 = (C + 3) / 4;
     const int cw = C4 < 256 ? (C4 <= 8 ? 8 : C4 <= 16 ? 16 : C4 <= 32 ? 32 : C4 <= 64 ? 64 : C4 <= 128 ? 128 : 256) : 256;
     const int rg = 256 / cw;                       // row groups working in parallel
@@ -717,10 +908,12 @@ template <int KL, bool HAS_BN>
 __global__ __launch_bounds__(NR_T) void narrow_fwd_kernel(const float* __restrict__ y, long long ldy, int rows, int K,
                                                          const float* __restrict__ coef, int relu,
                                                          const float* __restrict__ W, const float* __restrict__ bias, int N,
-                                                         float* __restrict__ out) {
+                                                         float* __restrict__ out, const SegTable st) {
     constexpr int RPW = 64 / KL;                      // rows per wave per step
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int kq = lane % KL, rsub = lane / KL, k = 4 * kq;
+    const RowBlock rb = row_block(st, (int)blockIdx.x, NR_ROWS);
+    if (HAS_BN) coef += (long long)rb.seg * ST_ROWS * K;
     float w[NMAX][4], cm[4], cs[4], cb[4];
 #pragma unroll
     for (int n = 0; n < NMAX; ++n)
@@ -732,8 +925,8 @@ __global__ __launch_bounds__(NR_T) void narrow_fwd_kernel(const float* __restric
         cs[j] = HAS_BN ? coef[ST_SCALE * K + k + j] : 1.0f;
         cb[j] = HAS_BN ? coef[ST_BETA * K + k + j] : 0.0f;
     }
-    const int r0 = blockIdx.x * NR_ROWS;
-    const int r1 = r0 + NR_ROWS < rows ? r0 + NR_ROWS : rows;
+    const int r0 = rb.row0;
+    const int r1 = r0 + NR_ROWS < rb.row_end ? r0 + NR_ROWS : rb.row_end;
     constexpr int RGF = (NR_T / 64) * RPW;
     const int iters = (r1 - r0 + RGF - 1) / RGF;   // uniform trip count: the DPP sums need every lane
     for (int it = 0; it < iters; ++it) {
@@ -766,12 +959,14 @@ __global__ __launch_bounds__(NR_T) void narrow_bwd_kernel(const float* __restric
                                                          const float* __restrict__ coef, int relu,
                                                          const float* __restrict__ W, float* __restrict__ dx,
                                                          float* __restrict__ part_s, float* __restrict__ part_w,
-                                                         float* __restrict__ part_b) {
+                                                         float* __restrict__ part_b, const SegTable st) {
     constexpr int RPW = 64 / KL, RG = (NR_T / 64) * RPW;       // row groups per block
     __shared__ float red[RG][KL][4 * NMAX + 8];
     __shared__ float redb[4][NMAX];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int kq = lane % KL, rsub = lane / KL, k = 4 * kq, rgp = wave * RPW + rsub;
+    const RowBlock rb = row_block(st, (int)blockIdx.x, NR_ROWS);
+    if (HAS_BN) coef += (long long)rb.seg * ST_ROWS * K;
     float w[NMAX][4], cm[4], cs[4], cb[4], ci[4];
 #pragma unroll
     for (int n = 0; n < NMAX; ++n)
@@ -789,8 +984,8 @@ __global__ __launch_bounds__(NR_T) void narrow_bwd_kernel(const float* __restric
     for (int n = 0; n < NMAX; ++n)
 #pragma unroll
         for (int j = 0; j < 4; ++j) dw[n][j] = 0.0f;
-    const int r0 = blockIdx.x * NR_ROWS;
-    const int r1 = r0 + NR_ROWS < rows ? r0 + NR_ROWS : rows;
+    const int r0 = rb.row0;
+    const int r1 = r0 + NR_ROWS < rb.row_end ? r0 + NR_ROWS : rb.row_end;
     for (int r = r0 + rgp; r < r1; r += RG) {
         const float4 v = *(const float4*)(y + (long long)r * ldy + k);
         const float e[4] = {v.x, v.y, v.z, v.w};
@@ -853,14 +1048,14 @@ __global__ __launch_bounds__(NR_T) void narrow_bwd_kernel(const float* __restric
     }
     // bias column sums: lanes with kq == 0 hold them, one per row group
     __syncthreads();
-    float* rb = &red[0][0][0];
+    float* rbias = &red[0][0][0];
     if (kq == 0)
 #pragma unroll
-        for (int n = 0; n < NMAX; ++n) rb[rgp * NMAX + n] = db[n];
+        for (int n = 0; n < NMAX; ++n) rbias[rgp * NMAX + n] = db[n];
     __syncthreads();
     if (threadIdx.x < (unsigned)N) {
         float a = 0.0f;
-        for (int gI = 0; gI < RG; ++gI) a += rb[gI * NMAX + threadIdx.x];
+        for (int gI = 0; gI < RG; ++gI) a += rbias[gI * NMAX + threadIdx.x];
         part_b[(long long)blockIdx.x * N + threadIdx.x] = a;
     }
     (void)redb;
@@ -873,6 +1068,51 @@ inline bool narrow_ok(const pn2_mlp_layer& L, bool last, int pool_k) {
 inline unsigned grid1d(long long total, int per_block = 256) {
     long long g = (total + per_block - 1) / per_block;
     return (unsigned)(g < 1 ? 1 : (g > 256 * 32 ? 256 * 32 : g));
+}
+
+// Host view of the row segments of a chain (pn2_segments of the C ABI; one segment = the ordinary batch).
+struct Segs {
+    int nseg;
+    const int32_t* row_off;   // host, nseg + 1 entries, row_off[0] == 0, row_off[nseg] == rows
+    int one[2];               // storage for the single-segment case
+};
+Segs make_segs(int rows, const pn2_segments* sg) {
+    Segs S{};
+    if (sg && sg->nseg > 1) {
+        S.nseg = sg->nseg;
+        S.row_off = sg->row_off;
+    } else {
+        S.nseg = 1;
+        S.one[0] = 0;
+        S.one[1] = rows;
+        S.row_off = nullptr;   // patched by the accessor below (S is returned by value)
+    }
+    return S;
+}
+inline int seg_off(const Segs& S, int i) { return S.row_off ? S.row_off[i] : S.one[i]; }
+bool segs_valid(int rows, const pn2_segments* sg, int pool_k) {
+    if (!sg || sg->nseg <= 1) return true;
+    if (sg->nseg > kMaxSegs || !sg->row_off || sg->row_off[0] != 0 || sg->row_off[sg->nseg] != rows) return false;
+    for (int i = 0; i < sg->nseg; ++i) {
+        const int n = sg->row_off[i + 1] - sg->row_off[i];
+        if (n <= 0 || (pool_k > 1 && n % pool_k)) return false;
+    }
+    return true;
+}
+// blocks of R rows that never straddle a segment; returns the table, *nblk = number of blocks
+SegTable make_table(const Segs& S, int R, int* nblk) {
+    SegTable t;
+    t.nseg = S.nseg;
+    int b = 0;
+    for (int i = 0; i < S.nseg; ++i) {
+        t.row_off[i] = seg_off(S, i);
+        t.blk_off[i] = b;
+        b += pn2::ceil_div(seg_off(S, i + 1) - seg_off(S, i), R);
+    }
+    t.row_off[S.nseg] = seg_off(S, S.nseg);
+    t.blk_off[S.nseg] = b;
+    *nblk = b;
+    return t;
 }
 
 inline void launch_slab_reduce(const float* slab, int nsplit, long long mn, float* out, hipStream_t s) {
@@ -916,8 +1156,6 @@ Operand act_operand(const Act& a, int rows, int cols) {
     return o;
 }
 
-inline long long grid_blocks(int M, int N, int tile) { return (long long)pn2::ceil_div(M, tile) * pn2::ceil_div(N, tile); }
-
 // Tile choice: 128-tiles unless they would leave most of the chip idle (deep levels have a few hundred rows).
 inline int pick_tile(int M, int N, int nsplit) {
     if (M <= 64 || N <= 64) return 64;   // a narrow output (the 128 -> 2/3 head convs) wastes less of a 64-tile
@@ -925,79 +1163,90 @@ inline int pick_tile(int M, int N, int nsplit) {
     return big >= 96 ? 128 : 64;
 }
 
+// Row-tiled roles (forward, dgrad): grid.x = row tiles of the segments; wgrad: grid.z = reduction ranges of the segments
+// (`g.k_per_split` rows each), grid.x tiles the output rows (= cout).
 template <bool A_T, int A_KIND, bool B_T, int B_KIND, int EPI, int TILE, bool VEC, int TEAMS = 1>
-int launch_gemm_tv(GemmArgs& g, int nsplit, hipStream_t s) {
-    dim3 grid(pn2::ceil_div(g.M, TILE), pn2::ceil_div(g.N, TILE), nsplit);
+int launch_gemm_tv(GemmArgs& g, const Segs& S, hipStream_t s, int* nblk_out) {
+    int nblk = 0;
+    const SegTable st = make_table(S, EPI == EPI_SLAB ? g.k_per_split : TILE, &nblk);
+    const dim3 grid = EPI == EPI_SLAB ? dim3(pn2::ceil_div(g.M, TILE), pn2::ceil_div(g.N, TILE), nblk)
+                                      : dim3(nblk, pn2::ceil_div(g.N, TILE), 1);
+    if (nblk_out) *nblk_out = nblk;
     const char* name = EPI == EPI_FWD ? "gemm_fwd" : EPI == EPI_STORE ? "gemm_dgrad" : "gemm_wgrad";
     const double mk = (double)g.M * g.K * (A_KIND == TR_DY ? 2 : 1), kn = (double)g.K * g.N * (B_KIND == TR_DY ? 2 : 1);
-    const double bytes = 4.0 * (mk + kn + (double)g.M * g.N * (EPI == EPI_SLAB ? nsplit : 1));
+    const double bytes = 4.0 * (mk + kn + (double)g.M * g.N * (EPI == EPI_SLAB ? nblk : 1));
     PN2_LAUNCH(name, bytes, 2.0 * g.M * g.N * g.K, (gemm_kernel<A_T, A_KIND, B_T, B_KIND, EPI, TILE, VEC, TEAMS>), grid,
-               dim3(NT * TEAMS), s, g);
+               dim3(NT * TEAMS), s, g, st);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
 
+inline long long grid_blocks(int M, int N, int tile) { return (long long)pn2::ceil_div(M, tile) * pn2::ceil_div(N, tile); }
+
 template <bool A_T, int A_KIND, bool B_T, int B_KIND, int EPI>
-int launch_gemm(GemmArgs& g, int nsplit, int tile, hipStream_t s) {
+int launch_gemm(GemmArgs& g, const Segs& S, int tile, hipStream_t s, int* nblk_out = nullptr) {
     const bool vec = vec_ok(g.A) && vec_ok(g.B);
     if (tile == 128)
-        return vec ? launch_gemm_tv<A_T, A_KIND, B_T, B_KIND, EPI, 128, true>(g, nsplit, s)
-                   : launch_gemm_tv<A_T, A_KIND, B_T, B_KIND, EPI, 128, false>(g, nsplit, s);
+        return vec ? launch_gemm_tv<A_T, A_KIND, B_T, B_KIND, EPI, 128, true>(g, S, s, nblk_out)
+                   : launch_gemm_tv<A_T, A_KIND, B_T, B_KIND, EPI, 128, false>(g, S, s, nblk_out);
     // small problem with a long contraction: split K over four teams inside the workgroup
     if (EPI != EPI_SLAB && g.K >= 8 * BK && (long long)grid_blocks(g.M, g.N, 64) <= 512)
-        return vec ? launch_gemm_tv<A_T, A_KIND, B_T, B_KIND, EPI, 64, true, 4>(g, nsplit, s)
-                   : launch_gemm_tv<A_T, A_KIND, B_T, B_KIND, EPI, 64, false, 4>(g, nsplit, s);
-    return vec ? launch_gemm_tv<A_T, A_KIND, B_T, B_KIND, EPI, 64, true>(g, nsplit, s)
-               : launch_gemm_tv<A_T, A_KIND, B_T, B_KIND, EPI, 64, false>(g, nsplit, s);
+        return vec ? launch_gemm_tv<A_T, A_KIND, B_T, B_KIND, EPI, 64, true, 4>(g, S, s, nblk_out)
+                   : launch_gemm_tv<A_T, A_KIND, B_T, B_KIND, EPI, 64, false, 4>(g, S, s, nblk_out);
+    return vec ? launch_gemm_tv<A_T, A_KIND, B_T, B_KIND, EPI, 64, true>(g, S, s, nblk_out)
+               : launch_gemm_tv<A_T, A_KIND, B_T, B_KIND, EPI, 64, false>(g, S, s, nblk_out);
 }
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 template <int KL>
-int launch_narrow_fwd_kl(const Act& in, int rows, const pn2_mlp_layer& L, float* out, hipStream_t s) {
-    const dim3 grid(pn2::ceil_div(rows, NR_ROWS)), block(NR_T);
+int launch_narrow_fwd_kl(const Act& in, int rows, const pn2_mlp_layer& L, float* out, const Segs& S, hipStream_t s) {
+    int nblk = 0;
+    const SegTable st = make_table(S, NR_ROWS, &nblk);
+    const dim3 grid(nblk), block(NR_T);
     const double bytes = 4.0 * rows * (L.cin + L.cout), flops = 2.0 * rows * L.cin * L.cout;
     if (in.coef)
         PN2_LAUNCH("narrow_fwd", bytes, flops, (narrow_fwd_kernel<KL, true>), grid, block, s, in.p, in.ld, rows, L.cin, in.coef,
-                   in.relu, L.weight, L.bias, L.cout, out);
+                   in.relu, L.weight, L.bias, L.cout, out, st);
     else
         PN2_LAUNCH("narrow_fwd", bytes, flops, (narrow_fwd_kernel<KL, false>), grid, block, s, in.p, in.ld, rows, L.cin, in.coef,
-                   in.relu, L.weight, L.bias, L.cout, out);
+                   in.relu, L.weight, L.bias, L.cout, out, st);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
-int launch_narrow_fwd(const Act& in, int rows, const pn2_mlp_layer& L, float* out, hipStream_t s) {
-    return L.cin == 64 ? launch_narrow_fwd_kl<16>(in, rows, L, out, s)
-                       : L.cin == 128 ? launch_narrow_fwd_kl<32>(in, rows, L, out, s) : launch_narrow_fwd_kl<64>(in, rows, L, out, s);
+int launch_narrow_fwd(const Act& in, int rows, const pn2_mlp_layer& L, float* out, const Segs& S, hipStream_t s) {
+    return L.cin == 64 ? launch_narrow_fwd_kl<16>(in, rows, L, out, S, s)
+                       : L.cin == 128 ? launch_narrow_fwd_kl<32>(in, rows, L, out, S, s) : launch_narrow_fwd_kl<64>(in, rows, L, out, S, s);
 }
 
 template <int KL>
 int launch_narrow_bwd_kl(const Act& in, int rows, const pn2_mlp_layer& L, const float* dout, float* dx, float* part_s,
-                         float* part_w, float* part_b, hipStream_t s) {
-    const dim3 grid(pn2::ceil_div(rows, NR_ROWS)), block(NR_T);
+                         float* part_w, float* part_b, const SegTable& st, int nblk, hipStream_t s) {
+    const dim3 grid(nblk), block(NR_T);
     const double bytes = 4.0 * rows * (2.0 * L.cin + L.cout), flops = 4.0 * rows * L.cin * L.cout;
     if (in.coef)
         PN2_LAUNCH("narrow_bwd", bytes, flops, (narrow_bwd_kernel<KL, true>), grid, block, s, dout, rows, L.cin, L.cout, in.p, in.ld,
-                   in.coef, in.relu, L.weight, dx, part_s, part_w, part_b);
+                   in.coef, in.relu, L.weight, dx, part_s, part_w, part_b, st);
     else
         PN2_LAUNCH("narrow_bwd", bytes, flops, (narrow_bwd_kernel<KL, false>), grid, block, s, dout, rows, L.cin, L.cout, in.p, in.ld,
-                   in.coef, in.relu, L.weight, dx, part_s, part_w, part_b);
+                   in.coef, in.relu, L.weight, dx, part_s, part_w, part_b, st);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
 int launch_narrow_bwd(const Act& in, int rows, const pn2_mlp_layer& L, const float* dout, float* dx, float* part_s,
-                      float* part_w, float* part_b, hipStream_t s) {
-    return L.cin == 64 ? launch_narrow_bwd_kl<16>(in, rows, L, dout, dx, part_s, part_w, part_b, s)
-           : L.cin == 128 ? launch_narrow_bwd_kl<32>(in, rows, L, dout, dx, part_s, part_w, part_b, s)
-                          : launch_narrow_bwd_kl<64>(in, rows, L, dout, dx, part_s, part_w, part_b, s);
+                      float* part_w, float* part_b, const SegTable& st, int nblk, hipStream_t s) {
+    return L.cin == 64 ? launch_narrow_bwd_kl<16>(in, rows, L, dout, dx, part_s, part_w, part_b, st, nblk, s)
+           : L.cin == 128 ? launch_narrow_bwd_kl<32>(in, rows, L, dout, dx, part_s, part_w, part_b, st, nblk, s)
+                          : launch_narrow_bwd_kl<64>(in, rows, L, dout, dx, part_s, part_w, part_b, st, nblk, s);
 }
 
 struct WgradPlan {
     int tile, nsplit, kps;
 };
 
-// dW = dY^T X reduces over `rows`; the reduction is cut into nsplit row ranges (one slab each, summed in fixed order)
-WgradPlan plan_wgrad(int rows, int cout, int cin) {
+// dW = dY^T X reduces over `rows`; the reduction is cut into row ranges of kps rows that stay inside one segment (one
+// slab each, summed in fixed order); nsplit = upper bound of the number of ranges (exact for one segment)
+WgradPlan plan_wgrad(int rows, int cout, int cin, int nseg) {
     const int tiles = pn2::ceil_div(cout, 128) * pn2::ceil_div(cin, 128);
     // one slab per workgroup; long reductions get two workgroups per CU (measured at 262144 rows, 128x128: 136 us with
     // 256 workgroups = one wavefront per SIMD, 111 us with 512, +3.6 us of slab reduction)
@@ -1006,25 +1255,58 @@ WgradPlan plan_wgrad(int rows, int cout, int cin) {
     int nsplit = target / tiles;
     if (nsplit < 1) nsplit = 1;
     const int kps = pn2::ceil_div(pn2::ceil_div(rows, nsplit), BK) * BK;
-    nsplit = pn2::ceil_div(rows, kps);
+    nsplit = pn2::ceil_div(rows, kps) + (nseg > 1 ? nseg : 0);
     return WgradPlan{pick_tile(cout, cin, nsplit), nsplit, kps};
+}
+
+// forward finalize of one BatchNorm layer: partial chunks of `ch` rows, `cpb` of them per row block of the table
+int launch_bn_finalize(const float* partial, const Segs& S, int tile, int rows, const pn2_mlp_layer& L, hipStream_t s) {
+    const int ch = tile / 2;
+    if (S.nseg == 1) {
+        PN2_LAUNCH("bn_finalize", 8.0 * pn2::ceil_div(rows, ch) * L.cout, 0, bn_finalize_kernel, dim3(L.cout), dim3(256), s,
+                   partial, rows, ch, L.cout, L.gamma, L.beta, L.running_mean, L.running_var, L.eps, L.momentum, L.stats);
+    } else {
+        int nblk = 0;
+        const SegTable st = make_table(S, tile, &nblk);
+        PN2_LAUNCH("bn_finalize", 16.0 * nblk * L.cout, 0, bn_finalize_seg_kernel, dim3(L.cout), dim3(256), s, partial, st, 2, ch,
+                   L.cout, L.gamma, L.beta, L.running_mean, L.running_var, L.eps, L.momentum, L.stats);
+    }
+    PN2_LAUNCH_CHECK();
+    return 0;
+}
+
+// backward finalize: `nblk` row blocks of `R` rows hold `cpb` partial chunks each
+int launch_bn_bwd_finalize(const float* partial, const Segs& S, int R, int cpb, int rows, const pn2_mlp_layer& L,
+                           hipStream_t s) {
+    int nblk = 0;
+    const SegTable st = make_table(S, R, &nblk);
+    if (S.nseg == 1)
+        PN2_LAUNCH("bn_bwd_finalize", 8.0 * nblk * cpb * L.cout, 0, bn_bwd_finalize_kernel, dim3(L.cout), dim3(256), s, partial,
+                   pn2::ceil_div(rows, R / cpb), rows, L.cout, L.stats, L.dgamma, L.dbeta);
+    else
+        PN2_LAUNCH("bn_bwd_finalize", 8.0 * nblk * cpb * L.cout, 0, bn_bwd_finalize_seg_kernel, dim3(L.cout), dim3(256), s,
+                   partial, st, cpb, R / cpb, L.cout, L.stats, L.dgamma, L.dbeta);
+    PN2_LAUNCH_CHECK();
+    return 0;
 }
 
 }  // namespace
 
 // ===================================================================================================== C ABI
-extern "C" size_t pn2_mlp_workspace_bytes(int rows, const pn2_mlp_layer* layers, int nlayers) {
+extern "C" size_t pn2_mlp_workspace_bytes(int rows, const pn2_mlp_layer* layers, int nlayers, int nseg) {
     if (rows <= 0 || !layers || nlayers <= 0) return 0;
+    if (nseg < 1) nseg = 1;
     size_t need = 0;
     for (int i = 0; i < nlayers; ++i) {
         const size_t cin = layers[i].cin, cout = layers[i].cout;
-        // per-row-chunk partials (forward stats, backward sums): chunks are >= 32 rows; channels up to max(cin, cout)
+        // per-row-chunk partials (forward stats, backward sums): chunks are >= 32 rows (+ 2 per segment boundary);
+        // channels up to max(cin, cout)
         const size_t cmax = cin > cout ? cin : cout;
-        const size_t part = (size_t)pn2::ceil_div(rows, 32) * 2 * cmax * sizeof(float);
+        const size_t part = ((size_t)pn2::ceil_div(rows, 32) + 2 * (size_t)nseg) * 2 * cmax * sizeof(float);
         const size_t cs = (size_t)pn2::ceil_div(rows, CS_ROWS) * cout * sizeof(float);         // bias column sums
-        const WgradPlan wp = plan_wgrad(rows, (int)cout, (int)cin);
+        const WgradPlan wp = plan_wgrad(rows, (int)cout, (int)cin, nseg);
         const size_t slab = (size_t)wp.nsplit * cout * cin * sizeof(float);
-        const size_t nblk = (size_t)pn2::ceil_div(rows, NR_ROWS);
+        const size_t nblk = (size_t)pn2::ceil_div(rows, NR_ROWS) + nseg;
         const size_t narrow = nblk * (2 * cin + cout * cin + cout) * sizeof(float);           // narrow_bwd partials
         size_t m = part > cs ? part : cs;
         m = m > slab ? m : slab;
@@ -1035,10 +1317,12 @@ extern "C" size_t pn2_mlp_workspace_bytes(int rows, const pn2_mlp_layer* layers,
 }
 
 extern "C" int pn2_mlp_chain_fwd_f32(const float* x, int64_t ldx, int rows, const pn2_mlp_layer* layers, int nlayers,
-                                     int training, int pool_k, float* out, int32_t* pool_arg, void* workspace,
-                                     size_t workspace_bytes, void* stream) {
+                                     int training, int pool_k, float* out, int32_t* pool_arg, const pn2_segments* segments,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !layers || nlayers <= 0 || rows <= 0 || !out || (pool_k > 1 && (!pool_arg || rows % pool_k))) return PN2_E_BADARG;
-    if (workspace_bytes < pn2_mlp_workspace_bytes(rows, layers, nlayers) || !workspace) return PN2_E_WORKSPACE;
+    if (!segs_valid(rows, segments, pool_k)) return PN2_E_BADARG;
+    const Segs S = make_segs(rows, training ? segments : nullptr);   // eval mode: one coefficient block serves every row
+    if (workspace_bytes < pn2_mlp_workspace_bytes(rows, layers, nlayers, S.nseg) || !workspace) return PN2_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     Act in{x, ldx, nullptr, 0};
     for (int i = 0; i < nlayers; ++i) {
@@ -1061,24 +1345,21 @@ extern "C" int pn2_mlp_chain_fwd_f32(const float* x, int64_t ldx, int rows, cons
         const int tile = pick_tile(rows, L.cout, 1);
         int st = 0;
         if (narrow_ok(L, last, pool_k) && in.ld % 4 == 0 && aligned16(in.p)) {
-            st = launch_narrow_fwd(in, rows, L, y, s);
+            st = launch_narrow_fwd(in, rows, L, y, S, s);
         } else {
-            st = in.coef ? launch_gemm<true, TR_BNRELU, true, TR_PLAIN, EPI_FWD>(g, 1, tile, s)
-                         : launch_gemm<true, TR_PLAIN, true, TR_PLAIN, EPI_FWD>(g, 1, tile, s);
+            st = in.coef ? launch_gemm<true, TR_BNRELU, true, TR_PLAIN, EPI_FWD>(g, S, tile, s)
+                         : launch_gemm<true, TR_PLAIN, true, TR_PLAIN, EPI_FWD>(g, S, tile, s);
         }
         if (st) return st;
         if (L.has_bn) {
             if (training) {
-                const int ch = tile / 2;
-                PN2_LAUNCH("bn_finalize", 8.0 * pn2::ceil_div(rows, ch) * L.cout, 0, bn_finalize_kernel, dim3(L.cout), dim3(256),
-                           s, (const float*)workspace, rows, ch, L.cout, L.gamma, L.beta, L.running_mean, L.running_var, L.eps,
-                           L.momentum, L.stats);
+                if ((st = launch_bn_finalize((const float*)workspace, S, tile, rows, L, s))) return st;
             } else {
                 if (!L.running_mean || !L.running_var) return PN2_E_BADARG;
                 PN2_LAUNCH("bn_eval_coef", 36.0 * L.cout, 0, bn_eval_coef_kernel, dim3(pn2::ceil_div(L.cout, 256)), dim3(256), s,
                            L.cout, L.gamma, L.beta, L.running_mean, L.running_var, L.eps, L.stats);
+                PN2_LAUNCH_CHECK();
             }
-            PN2_LAUNCH_CHECK();
             in = Act{y, L.cout, L.stats, L.relu};
         } else {
             if (L.relu && !last) return PN2_E_BADARG;  // ReLU without BatchNorm only exists fused into a BN layer here
@@ -1087,11 +1368,17 @@ extern "C" int pn2_mlp_chain_fwd_f32(const float* x, int64_t ldx, int rows, cons
         if (last && !direct_out) {
             const int C = L.cout;
             if (!L.has_bn || C % 4) return PN2_E_BADARG;
+            int nblk = 0;
             if (pool_k > 1) {
                 const long long groups = rows / pool_k;
+                const SegTable tb = make_table(S, pool_k, &nblk);
                 PN2_LAUNCH("bn_relu_maxpool", 4.0 * rows * C + 8.0 * groups * C, 0, bn_relu_maxpool_kernel,
                            dim3(grid1d(groups * C)), dim3(256), s, (const float*)y, groups, pool_k, C, (const float*)L.stats,
-                           L.relu, out, pool_arg);
+                           L.relu, out, pool_arg, tb);
+            } else if (S.nseg > 1) {
+                const SegTable tb = make_table(S, APPLY_R, &nblk);
+                PN2_LAUNCH("bn_relu_apply", 8.0 * rows * C, 0, bn_relu_apply_seg_kernel, dim3(nblk), dim3(256), s, (const float*)y, tb,
+                           C, (const float*)L.stats, L.relu, out);
             } else {
                 PN2_LAUNCH("bn_relu_apply", 8.0 * rows * C, 0, bn_relu_apply_kernel, dim3(grid1d((long long)rows * C / 4)),
                            dim3(256), s, (const float*)y, (long long)rows * C / 4, C, (const float*)L.stats, L.relu, out);
@@ -1104,10 +1391,12 @@ extern "C" int pn2_mlp_chain_fwd_f32(const float* x, int64_t ldx, int rows, cons
 
 extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, const pn2_mlp_layer* layers, int nlayers,
                                      int pool_k, const float* dout, const int32_t* pool_arg, float* dx, int64_t lddx,
-                                     float* scratch_a, float* scratch_b, void* workspace, size_t workspace_bytes,
-                                     void* stream) {
+                                     float* scratch_a, float* scratch_b, const pn2_segments* segments, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
     if (!x || !layers || nlayers <= 0 || rows <= 0 || !dout || !scratch_a || !scratch_b) return PN2_E_BADARG;
-    if (workspace_bytes < pn2_mlp_workspace_bytes(rows, layers, nlayers) || !workspace) return PN2_E_WORKSPACE;
+    if (!segs_valid(rows, segments, pool_k)) return PN2_E_BADARG;
+    const Segs S = make_segs(rows, segments);
+    if (workspace_bytes < pn2_mlp_workspace_bytes(rows, layers, nlayers, S.nseg) || !workspace) return PN2_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     float* ws = (float*)workspace;
     // dz of the last layer: upstream gradient, or the max-pool scatter of it
@@ -1125,29 +1414,30 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
         dz = bufs[which];
         which ^= 1;
     }
-    int fused_nblk = 0;  // > 0: the BatchNorm-backward partials of the current layer are already in ws (that many blocks)
+    // BatchNorm-backward partials of the current layer already in ws?  (R, cpb): row-block size and chunks per block
+    int fused_R = 0, fused_cpb = 0;
     for (int i = nlayers - 1; i >= 0; --i) {
         const pn2_mlp_layer& L = layers[i];
         const bool last = i == nlayers - 1;
         const float* y = (last && !L.has_bn && pool_k <= 1) ? nullptr : L.y;
         // ---- BatchNorm backward reductions -> coefficients a, b and dgamma, dbeta
         if (L.has_bn) {
-            int nblk;
-            if (fused_nblk) {
-                nblk = fused_nblk;   // written by the dgrad epilogue (or the narrow backward kernel) of layer i + 1
-            } else {
-                nblk = pn2::ceil_div(rows, RB);
+            int R = fused_R, cpb = fused_cpb, st;
+            if (!fused_R) {   // otherwise written by the dgrad epilogue (or the narrow backward kernel) of layer i + 1
+                R = RB;
+                cpb = 1;
+                int nblk = 0;
+                const SegTable tb = make_table(S, RB, &nblk);
                 const bool vec = (L.cout % 4 == 0) && (lddz % 4 == 0) && aligned16(dz) && aligned16(y);
                 if (vec)
                     PN2_LAUNCH("bn_bwd_reduce", 8.0 * rows * L.cout, 0, (bn_bwd_reduce_kernel<true>), dim3(nblk), dim3(256), s, dz,
-                               lddz, y, (long long)L.cout, rows, L.cout, (const float*)L.stats, L.relu, ws);
+                               lddz, y, (long long)L.cout, rows, L.cout, (const float*)L.stats, L.relu, ws, tb);
                 else
                     PN2_LAUNCH("bn_bwd_reduce", 8.0 * rows * L.cout, 0, (bn_bwd_reduce_kernel<false>), dim3(nblk), dim3(256), s, dz,
-                               lddz, y, (long long)L.cout, rows, L.cout, (const float*)L.stats, L.relu, ws);
+                               lddz, y, (long long)L.cout, rows, L.cout, (const float*)L.stats, L.relu, ws, tb);
+                PN2_LAUNCH_CHECK();
             }
-            PN2_LAUNCH("bn_bwd_finalize", 8.0 * nblk * L.cout, 0, bn_bwd_finalize_kernel, dim3(L.cout), dim3(256), s,
-                       (const float*)ws, nblk, rows, L.cout, L.stats, L.dgamma, L.dbeta);
-            PN2_LAUNCH_CHECK();
+            if ((st = launch_bn_bwd_finalize((const float*)ws, S, R, cpb, rows, L, s))) return st;
         } else if (L.dbias && !(narrow_ok(L, last, pool_k) && lddz == L.cout)) {
             const int nblk = pn2::ceil_div(rows, CS_ROWS);
             PN2_LAUNCH("colsum", 4.0 * rows * L.cout, 0, colsum_kernel, dim3(nblk), dim3(256), s, dz, lddz, rows, L.cout, ws);
@@ -1155,20 +1445,21 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
                        (const float*)ws, nblk, L.cout, L.dbias);
             PN2_LAUNCH_CHECK();
         }
-        fused_nblk = 0;
+        fused_R = fused_cpb = 0;
         // layer input as an activation source
         Act in = i == 0 ? Act{x, ldx, nullptr, 0}
                         : Act{layers[i - 1].y, layers[i - 1].cout, layers[i - 1].has_bn ? layers[i - 1].stats : nullptr,
                               layers[i - 1].relu};
         // ---- narrow last layer: one vector-ALU pass does dgrad, wgrad, bias sums and the previous layer's BN sums
         if (narrow_ok(L, last, pool_k) && lddz == L.cout && in.ld % 4 == 0 && aligned16(in.p)) {
-            const int nblk = pn2::ceil_div(rows, NR_ROWS);
+            int nblk = 0;
+            const SegTable tb = make_table(S, NR_ROWS, &nblk);
             float* part_s = ws;
             float* part_w = part_s + (size_t)nblk * 2 * L.cin;
             float* part_b = part_w + (size_t)nblk * L.cout * L.cin;
             float* target = i > 0 ? bufs[which] : (dx ? dx : bufs[which]);
             if (i == 0 && dx && lddx != L.cin) return PN2_E_BADARG;
-            int st = launch_narrow_bwd(in, rows, L, dz, target, part_s, part_w, part_b, s);
+            int st = launch_narrow_bwd(in, rows, L, dz, target, part_s, part_w, part_b, tb, nblk, s);
             if (st) return st;
             if (L.dweight)
                 launch_slab_reduce((const float*)part_w, nblk, (long long)L.cout * L.cin, L.dweight, s);
@@ -1176,7 +1467,10 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
                 PN2_LAUNCH("colsum_finalize", 4.0 * nblk * L.cout, 0, colsum_finalize_kernel, dim3(L.cout), dim3(64), s,
                            (const float*)part_b, nblk, L.cout, L.dbias);
             PN2_LAUNCH_CHECK();
-            if (i > 0 && layers[i - 1].has_bn) fused_nblk = nblk;
+            if (i > 0 && layers[i - 1].has_bn) {
+                fused_R = NR_ROWS;
+                fused_cpb = 1;
+            }
             dz = target;
             lddz = L.cin;
             which ^= 1;
@@ -1193,7 +1487,7 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
         }
         // ---- wgrad: dW[cout][cin] += dY^T X, reduction over rows split across blocks
         if (L.dweight) {
-            const WgradPlan wp = plan_wgrad(rows, L.cout, L.cin);
+            const WgradPlan wp = plan_wgrad(rows, L.cout, L.cin, S.nseg);
             GemmArgs g{};
             g.A = dy;                       // [rows = K][cout = M], direct layout
             g.B = act_operand(in, rows, L.cin);
@@ -1203,15 +1497,15 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
             g.C = ws;
             g.ldc = L.cin;
             g.k_per_split = wp.kps;
-            int st;
+            int st, nsplit = 0;
             if (L.has_bn)
-                st = in.coef ? launch_gemm<false, TR_DY, false, TR_BNRELU, EPI_SLAB>(g, wp.nsplit, wp.tile, s)
-                             : launch_gemm<false, TR_DY, false, TR_PLAIN, EPI_SLAB>(g, wp.nsplit, wp.tile, s);
+                st = in.coef ? launch_gemm<false, TR_DY, false, TR_BNRELU, EPI_SLAB>(g, S, wp.tile, s, &nsplit)
+                             : launch_gemm<false, TR_DY, false, TR_PLAIN, EPI_SLAB>(g, S, wp.tile, s, &nsplit);
             else
-                st = in.coef ? launch_gemm<false, TR_PLAIN, false, TR_BNRELU, EPI_SLAB>(g, wp.nsplit, wp.tile, s)
-                             : launch_gemm<false, TR_PLAIN, false, TR_PLAIN, EPI_SLAB>(g, wp.nsplit, wp.tile, s);
+                st = in.coef ? launch_gemm<false, TR_PLAIN, false, TR_BNRELU, EPI_SLAB>(g, S, wp.tile, s, &nsplit)
+                             : launch_gemm<false, TR_PLAIN, false, TR_PLAIN, EPI_SLAB>(g, S, wp.tile, s, &nsplit);
             if (st) return st;
-            launch_slab_reduce((const float*)ws, wp.nsplit, (long long)L.cout * L.cin, L.dweight, s);
+            launch_slab_reduce((const float*)ws, nsplit, (long long)L.cout * L.cin, L.dweight, s);
             PN2_LAUNCH_CHECK();
         }
         // ---- dgrad: dX[rows][cin] = dY W; when the previous layer has a BatchNorm its backward column sums are
@@ -1235,10 +1529,11 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
                 g.ldey = layers[i - 1].cout;
                 g.ecoef = layers[i - 1].stats;
                 g.erelu = layers[i - 1].relu;
-                fused_nblk = pn2::ceil_div(rows, tile / 2);
+                fused_R = tile;
+                fused_cpb = 2;
             }
-            int st = L.has_bn ? launch_gemm<true, TR_DY, false, TR_PLAIN, EPI_STORE>(g, 1, tile, s)
-                              : launch_gemm<true, TR_PLAIN, false, TR_PLAIN, EPI_STORE>(g, 1, tile, s);
+            int st = L.has_bn ? launch_gemm<true, TR_DY, false, TR_PLAIN, EPI_STORE>(g, S, tile, s)
+                              : launch_gemm<true, TR_PLAIN, false, TR_PLAIN, EPI_STORE>(g, S, tile, s);
             if (st) return st;
             dz = target;
             lddz = ldt;

@@ -135,4 +135,22 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
 
 inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// Ragged batches (whole-tree execution, see pn2_hip.h "Ragged clouds"): cloud b holds n_b = coff[b+1] - coff[b] points,
+// stored CHANNEL-FIRST inside one flat buffer of CH planes per cloud: element (b, i, ch) at CH*coff[b] + ch*n_b + i --
+// exactly the bytes of the reference's per-mini-batch [B_j, CH, N_j] tensors laid end to end.  With coff == nullptr
+// the regular (b*sb + i*sn + ch*sc) addressing applies.
+struct CloudView {
+    const float* p;
+    int64_t sn, sc;
+    int n;
+};
+__device__ __forceinline__ CloudView cloud_view(const float* base, int64_t sb, int64_t sn, int64_t sc, int N, const int* coff,
+                                                int b, int CH) {
+    if (coff) {
+        const int o = coff[b], n = coff[b + 1] - o;
+        return CloudView{base + (int64_t)CH * o, 1, n, n};
+    }
+    return CloudView{base + (int64_t)b * sb, sn, sc, N};
+}
+
 }  // namespace pn2

@@ -23,16 +23,22 @@ template <int P>
 __global__ __launch_bounds__(kBlock) void three_nn_kernel(const float* __restrict__ xyz1, int64_t ab, int64_t an, int64_t ac,
                                                           const float* __restrict__ xyz2, int64_t bb, int64_t bn, int64_t bc,
                                                           int N, int S, int32_t* __restrict__ out_idx,
-                                                          float* __restrict__ out_w, float* __restrict__ out_dist) {
+                                                          float* __restrict__ out_w, float* __restrict__ out_dist,
+                                                          const int* __restrict__ coff) {
     __shared__ float4 tile[kTile + 1];  // +1: the loop below reads one entry ahead
     const int b = blockIdx.y;
+    // ragged batch: the dense side is a flat channel-first buffer, outputs are packed rows (coff[b] + n)
+    const pn2::CloudView cv = pn2::cloud_view(xyz1, ab, an, ac, N, coff, b, 3);
+    N = cv.n;
+    if ((int)(blockIdx.x * P * kBlock) >= N) return;   // uniform: the grid is sized for the longest cloud
+    const size_t row0 = coff ? (size_t)coff[b] : (size_t)b * N;
     float px[P], py[P], pz[P], pn[P], d0[P], d1[P], d2[P];
     int i0[P], i1[P], i2[P];
 #pragma unroll
     for (int j = 0; j < P; ++j) {
         const int n = (blockIdx.x * P + j) * kBlock + threadIdx.x;
-        const float* p = xyz1 + (int64_t)b * ab + (int64_t)(n < N ? n : 0) * an;
-        px[j] = p[0], py[j] = p[ac], pz[j] = p[2 * ac];
+        const float* p = cv.p + (int64_t)(n < N ? n : 0) * cv.sn;
+        px[j] = p[0], py[j] = p[cv.sc], pz[j] = p[2 * cv.sc];
         pn[j] = pn2::norm2(px[j], py[j], pz[j]);
         d0[j] = d1[j] = d2[j] = __builtin_inff();
         i0[j] = i1[j] = i2[j] = 0;
@@ -93,7 +99,7 @@ __global__ __launch_bounds__(kBlock) void three_nn_kernel(const float* __restric
 #pragma unroll
     for (int j = 0; j < P; ++j) {
         const int n = (blockIdx.x * P + j) * kBlock + threadIdx.x;
-        const size_t o = ((size_t)b * N + n) * 3;
+        const size_t o = (row0 + n) * 3;
         if (n < N) {
         out_idx[o] = i0[j];
         out_idx[o + 1] = i1[j];
@@ -136,12 +142,19 @@ __global__ __launch_bounds__(kBlock) void three_interpolate_kernel(const float* 
                                                                    int64_t pc, const int32_t* __restrict__ idx,
                                                                    const float* __restrict__ w, int N, int S, int D,
                                                                    float* __restrict__ out, int64_t out_stride,
-                                                                   int64_t out_offset, long long total, int32_t* status) {
+                                                                   int64_t out_offset, long long total, int32_t* status,
+                                                                   const int* __restrict__ coff) {
     const int DV = D / V;
-    for (long long e = (long long)blockIdx.x * kBlock + threadIdx.x; e < total; e += (long long)gridDim.x * kBlock) {
-        const long long r = e / DV;  // (b, n)
-        const int c = (int)(e - r * DV) * V;
-        const int b = (int)(r / N);
+    // ragged batch: blockIdx.y = cloud, the x-range covers the longest cloud; idx / w / out are packed rows
+    long long e_begin = (long long)blockIdx.x * kBlock + threadIdx.x, e_step = (long long)gridDim.x * kBlock, row0 = 0;
+    if (coff) {
+        row0 = coff[blockIdx.y];
+        total = (long long)(coff[blockIdx.y + 1] - coff[blockIdx.y]) * DV;
+    }
+    for (long long e = e_begin; e < total; e += e_step) {
+        const long long r = row0 + e / DV;  // (b, n)
+        const int c = (int)(e % DV) * V;
+        const int b = coff ? (int)blockIdx.y : (int)(r / N);
         int j0 = idx[r * 3], j1 = idx[r * 3 + 1], j2 = idx[r * 3 + 2];
         if (((unsigned)j0 >= (unsigned)S) | ((unsigned)j1 >= (unsigned)S) | ((unsigned)j2 >= (unsigned)S)) {
             // untrusted index: do not follow it (row 0 instead) and tell the caller (PN2_STATUS_BAD_INDEX)
@@ -184,13 +197,16 @@ constexpr int TIG_T = 1024;
 // becoming an out-of-bounds LDS / global access
 __device__ __forceinline__ int clamp_idx(int j, int S) { return (unsigned)j < (unsigned)S ? j : 0; }
 __global__ __launch_bounds__(TIG_T) void tig_count_kernel(const int32_t* __restrict__ idx, int N, int S, int per_block,
-                                                          int* __restrict__ hist) {
+                                                          int* __restrict__ hist, const int* __restrict__ coff) {
     extern __shared__ int lh[];  // [S]
     const int b = blockIdx.y;
+    const long long row0 = coff ? coff[b] : (long long)b * N;   // ragged batch: packed rows, n_b = coff[b+1] - coff[b]
+    if (coff) N = coff[b + 1] - coff[b];
+    if ((long long)blockIdx.x * per_block >= 3LL * N) return;   // uniform
     for (int e = threadIdx.x; e < S; e += TIG_T) lh[e] = 0;
     __syncthreads();
     const long long p0 = (long long)blockIdx.x * per_block, p1 = p0 + per_block < 3LL * N ? p0 + per_block : 3LL * N;
-    const int32_t* ib = idx + (long long)b * 3 * N;
+    const int32_t* ib = idx + row0 * 3;
     for (long long e = p0 + threadIdx.x; e < p1; e += TIG_T) atomicAdd(&lh[clamp_idx(ib[e], S)], 1);
     __syncthreads();
     for (int e = threadIdx.x; e < S; e += TIG_T)
@@ -245,14 +261,17 @@ __global__ __launch_bounds__(1024) void tig_scan_kernel(const int* __restrict__ 
 // that range with LDS atomics.
 __global__ __launch_bounds__(TIG_T) void tig_fill_kernel(const int32_t* __restrict__ idx, const float* __restrict__ w, int N,
                                                          int S, int per_block, int* __restrict__ cursor,
-                                                         int2* __restrict__ list) {
+                                                         int2* __restrict__ list, const int* __restrict__ coff) {
     extern __shared__ int lh[];  // [S] counts, then [S] running positions
     const int b = blockIdx.y;
+    const long long row0 = coff ? coff[b] : (long long)b * N;
+    if (coff) N = coff[b + 1] - coff[b];
+    if ((long long)blockIdx.x * per_block >= 3LL * N) return;   // uniform
     for (int e = threadIdx.x; e < S; e += TIG_T) lh[e] = 0;
     __syncthreads();
     const long long p0 = (long long)blockIdx.x * per_block, p1 = p0 + per_block < 3LL * N ? p0 + per_block : 3LL * N;
-    const int32_t* ib = idx + (long long)b * 3 * N;
-    const float* wb = w + (long long)b * 3 * N;
+    const int32_t* ib = idx + row0 * 3;
+    const float* wb = w + row0 * 3;
     for (long long e = p0 + threadIdx.x; e < p1; e += TIG_T) atomicAdd(&lh[clamp_idx(ib[e], S)], 1);
     __syncthreads();
     for (int e = threadIdx.x; e < S; e += TIG_T) {
@@ -262,7 +281,7 @@ __global__ __launch_bounds__(TIG_T) void tig_fill_kernel(const int32_t* __restri
     __syncthreads();
     for (long long e = p0 + threadIdx.x; e < p1; e += TIG_T) {
         const int pos = atomicAdd(&lh[clamp_idx(ib[e], S)], 1);
-        list[pos] = make_int2((int)((long long)b * N + e / 3), __float_as_int(wb[e]));
+        list[pos] = make_int2((int)(row0 + e / 3), __float_as_int(wb[e]));
     }
 }
 
@@ -353,7 +372,7 @@ extern "C" int pn2_three_nn_f32(const float* xyz1, int64_t ab, int64_t an, int64
 #define PN2_TNN_CASE(P_)                                                                                              \
     if (P == P_)                                                                                                      \
         PN2_LAUNCH("three_nn", tnn_bytes, 8.0 * B * (double)N * S, (three_nn_kernel<P_>), dim3(pn2::ceil_div(N, kBlock * P_), B), dim3(kBlock), \
-                   (hipStream_t)stream, xyz1, ab, an, ac, xyz2, bb, bn, bc, N, S, out_idx, out_w, out_dist);
+                   (hipStream_t)stream, xyz1, ab, an, ac, xyz2, bb, bn, bc, N, S, out_idx, out_w, out_dist, (const int*)nullptr);
     PN2_TNN_CASE(1)
     PN2_TNN_CASE(2)
     PN2_TNN_CASE(4)
@@ -385,11 +404,11 @@ extern "C" int pn2_three_interpolate_f32(const float* points2, int64_t pb, int64
     if (vec) {
         const long long total = (long long)B * N * (D / 4);
         PN2_LAUNCH("three_interpolate", ti_bytes, 0, (three_interpolate_kernel<4>), dim3(grid_for(total)), dim3(kBlock), s,
-                   points2, pb, pn, pc, idx, w, N, S, D, out, out_stride, out_offset, total, status);
+                   points2, pb, pn, pc, idx, w, N, S, D, out, out_stride, out_offset, total, status, (const int*)nullptr);
     } else {
         const long long total = (long long)B * N * D;
         PN2_LAUNCH("three_interpolate", ti_bytes, 0, (three_interpolate_kernel<1>), dim3(grid_for(total)), dim3(kBlock), s,
-                   points2, pb, pn, pc, idx, w, N, S, D, out, out_stride, out_offset, total, status);
+                   points2, pb, pn, pc, idx, w, N, S, D, out, out_stride, out_offset, total, status, (const int*)nullptr);
     }
     PN2_LAUNCH_CHECK();
     return 0;
@@ -398,35 +417,39 @@ extern "C" int pn2_three_interpolate_f32(const float* points2, int64_t pb, int64
 // bucketing pays off once the op is large; below this many atomics the direct kernel is faster
 static bool tig_sorted(int B, int N, int S, int D) { return (long long)B * N * D >= (1LL << 22) && S <= 8192 && B <= 65535; }
 
-extern "C" size_t pn2_three_interpolate_grad_workspace_bytes(int B, int N, int S, int D) {
-    if (B <= 0 || N <= 0 || S <= 0 || D <= 0 || !tig_sorted(B, N, S, D)) return 16;
-    // hist, offs (+1), cursor: ints; list: (row, weight) pairs
-    return (size_t)(4 * ((size_t)B * S + 4)) * sizeof(int) + 16 + (size_t)B * N * 3 * sizeof(int2);
+// hist, offs (+1), cursor, coffs: ints; list: (row, weight) pairs
+static size_t tig_workspace(int B, long long rows, int S) {
+    return (size_t)(4 * ((size_t)B * S + 4)) * sizeof(int) + 16 + (size_t)rows * 3 * sizeof(int2);
 }
 
-extern "C" int pn2_three_interpolate_grad_f32(const float* dout, int64_t out_stride, int64_t out_offset,
-                                              const int32_t* idx, const float* w, int B, int N, int S, int D,
-                                              float* dpoints2, void* workspace, size_t workspace_bytes, void* stream) {
-    if (!dout || !idx || !w || !dpoints2 || B <= 0 || N <= 0 || S <= 0 || D <= 0 || out_stride < out_offset + D)
-        return PN2_E_BADARG;
+extern "C" size_t pn2_three_interpolate_grad_workspace_bytes(int B, int N, int S, int D) {
+    if (B <= 0 || N <= 0 || S <= 0 || D <= 0 || !tig_sorted(B, N, S, D)) return 16;
+    return tig_workspace(B, (long long)B * N, S);
+}
+
+// Shared body: regular batches (coff == nullptr, B clouds of N rows) and ragged ones (coff [B+1], N = longest cloud, `rows`
+// packed rows in total).  Ragged batches always take the bucketed path.
+static int tig_run(const float* dout, int64_t out_stride, int64_t out_offset, const int32_t* idx, const float* w, int B, int N,
+                   int S, int D, float* dpoints2, void* workspace, size_t workspace_bytes, void* stream, const int* coff,
+                   long long rows) {
     hipStream_t s = (hipStream_t)stream;
     PN2_HIP_CHECK(hipMemsetAsync(dpoints2, 0, (size_t)B * S * D * sizeof(float), s));
-    const double bytes = (double)B * N * (36.0 + 4.0 * D) + 4.0 * B * S * D;
-    if (!tig_sorted(B, N, S, D)) {
+    const double bytes = (double)rows * (36.0 + 4.0 * D) + 4.0 * B * S * D;
+    if (!coff && !tig_sorted(B, N, S, D)) {
         const long long total = (long long)B * N * D;
         PN2_LAUNCH("three_interpolate_grad", bytes, 0, three_interpolate_grad_global_kernel, dim3(grid_for(total)), dim3(kBlock), s,
                    dout, out_stride, out_offset, idx, w, N, S, D, dpoints2, total);
         PN2_LAUNCH_CHECK();
         return 0;
     }
-    if (!workspace || workspace_bytes < pn2_three_interpolate_grad_workspace_bytes(B, N, S, D)) return PN2_E_WORKSPACE;
+    if (!workspace || workspace_bytes < tig_workspace(B, rows, S)) return PN2_E_WORKSPACE;
     const int BS = B * S;
     int* hist = (int*)workspace;
     int* offs = hist + BS + 4;
     int* cursor = offs + BS + 4;
     int* coffs = cursor + BS + 4;
     int2* list = (int2*)(((uintptr_t)(coffs + BS + 4) + 15) & ~(uintptr_t)15);
-    const long long pairs = (long long)B * N * 3;
+    const long long pairs = rows * 3;
     PN2_HIP_CHECK(hipMemsetAsync(hist, 0, (size_t)(BS + 4) * sizeof(int), s));
     // ~64 workgroups per launch keep the per-destination global atomics few; S ints of LDS each
     int shares = 64 / B;
@@ -436,12 +459,12 @@ extern "C" int pn2_three_interpolate_grad_f32(const float* dout, int64_t out_str
     const size_t lds = (size_t)S * sizeof(int);
     {
         pn2::prof::Scope sc_("tig_count", s, 8.0 * pairs, 0);
-        hipLaunchKernelGGL(tig_count_kernel, dim3(shares, B), dim3(TIG_T), lds, s, idx, N, S, per_block, hist);
+        hipLaunchKernelGGL(tig_count_kernel, dim3(shares, B), dim3(TIG_T), lds, s, idx, N, S, per_block, hist, coff);
     }
     PN2_LAUNCH("tig_scan", 12.0 * BS, 0, tig_scan_kernel, dim3(1), dim3(1024), s, (const int*)hist, BS, offs, cursor, coffs);
     {
         pn2::prof::Scope sc_("tig_fill", s, 24.0 * pairs, 0);
-        hipLaunchKernelGGL(tig_fill_kernel, dim3(shares, B), dim3(TIG_T), lds, s, idx, w, N, S, per_block, cursor, list);
+        hipLaunchKernelGGL(tig_fill_kernel, dim3(shares, B), dim3(TIG_T), lds, s, idx, w, N, S, per_block, cursor, list, coff);
     }
     // sum over destinations of ceil(len / 64) <= pairs / 64 + B*S: wavefronts beyond the real chunk count exit at once
     const long long waves = pairs / TIG_CHUNK + BS + 1;
@@ -450,4 +473,67 @@ extern "C" int pn2_three_interpolate_grad_f32(const float* dout, int64_t out_str
                s, dout, out_stride, out_offset, (const int*)offs, (const int*)coffs, (const int2*)list, BS, D, dpoints2);
     PN2_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int pn2_three_interpolate_grad_f32(const float* dout, int64_t out_stride, int64_t out_offset,
+                                              const int32_t* idx, const float* w, int B, int N, int S, int D,
+                                              float* dpoints2, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!dout || !idx || !w || !dpoints2 || B <= 0 || N <= 0 || S <= 0 || D <= 0 || out_stride < out_offset + D)
+        return PN2_E_BADARG;
+    return tig_run(dout, out_stride, out_offset, idx, w, B, N, S, D, dpoints2, workspace, workspace_bytes, stream, nullptr,
+                   (long long)B * N);
+}
+
+// ------------------------------------------------------------------------------------------------ ragged batches
+// Whole-tree execution (pn2_hip.h "Ragged clouds"): the dense side is C clouds of n_b = coff[b+1] - coff[b] points in one
+// flat channel-first buffer, the sampled side is regular [C,S,*]; idx / w / interpolated rows are PACKED rows
+// (row = coff[b] + n), `rows` = coff[C].
+extern "C" int pn2_three_nn_ragged_f32(const float* xyz1_cf, const int32_t* coff, const float* xyz2, int C, int n_max, int S,
+                                       int32_t* out_idx, float* out_w, void* stream) {
+    if (!xyz1_cf || !coff || !xyz2 || !out_idx || !out_w || C <= 0 || n_max <= 0 || S < 3 || C > 65535) return PN2_E_BADARG;
+    PN2_LAUNCH("three_nn", (double)C * (48.0 * n_max + 12.0 * S), 8.0 * C * (double)n_max * S, (three_nn_kernel<1>),
+               dim3(pn2::ceil_div(n_max, kBlock), C), dim3(kBlock), (hipStream_t)stream, xyz1_cf, 0, 1, 0, xyz2, (int64_t)S * 3, 3,
+               1, n_max, S, out_idx, out_w, (float*)nullptr, (const int*)coff);
+    PN2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pn2_three_interpolate_ragged_f32(const float* points2, const int32_t* idx, const float* w, const int32_t* coff,
+                                                int C, int n_max, long long rows, int S, int D, float* out, int64_t out_stride,
+                                                int64_t out_offset, int32_t* status, void* stream) {
+    if (!points2 || !idx || !w || !coff || !out || C <= 0 || n_max <= 0 || rows <= 0 || S <= 0 || D <= 0 ||
+        out_stride < out_offset + D || C > 65535)
+        return PN2_E_BADARG;
+    const bool vec = D % 4 == 0 && out_stride % 4 == 0 && out_offset % 4 == 0 && ((uintptr_t)points2 % 16 == 0) &&
+                     ((uintptr_t)out % 16 == 0);
+    hipStream_t s = (hipStream_t)stream;
+    const double ti_bytes = (double)rows * (36.0 + 4.0 * D) + 4.0 * C * S * D;
+    const int64_t pb = (int64_t)S * D, pn = D;
+    if (vec) {
+        const long long per = (long long)n_max * (D / 4);
+        PN2_LAUNCH("three_interpolate", ti_bytes, 0, (three_interpolate_kernel<4>), dim3(grid_for(per), C), dim3(kBlock), s, points2,
+                   pb, pn, (int64_t)1, idx, w, n_max, S, D, out, out_stride, out_offset, per, status, (const int*)coff);
+    } else {
+        const long long per = (long long)n_max * D;
+        PN2_LAUNCH("three_interpolate", ti_bytes, 0, (three_interpolate_kernel<1>), dim3(grid_for(per), C), dim3(kBlock), s, points2,
+                   pb, pn, (int64_t)1, idx, w, n_max, S, D, out, out_stride, out_offset, per, status, (const int*)coff);
+    }
+    PN2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t pn2_three_interpolate_grad_ragged_workspace_bytes(int C, long long rows, int S) {
+    if (C <= 0 || rows <= 0 || S <= 0) return 16;
+    return tig_workspace(C, rows, S);
+}
+
+extern "C" int pn2_three_interpolate_grad_ragged_f32(const float* dout, int64_t out_stride, int64_t out_offset, const int32_t* idx,
+                                                     const float* w, const int32_t* coff, int C, int n_max, long long rows, int S,
+                                                     int D, float* dpoints2, void* workspace, size_t workspace_bytes,
+                                                     void* stream) {
+    if (!dout || !idx || !w || !coff || !dpoints2 || C <= 0 || n_max <= 0 || rows <= 0 || S <= 0 || S > 8192 || D <= 0 ||
+        out_stride < out_offset + D || C > 65535)
+        return PN2_E_BADARG;
+    return tig_run(dout, out_stride, out_offset, idx, w, C, n_max, S, D, dpoints2, workspace, workspace_bytes, stream,
+                   (const int*)coff, rows);
 }

@@ -60,6 +60,9 @@ class _ChainFn(torch.autograd.Function):
         rows, cin0 = x.shape
         n = len(meta["layers"])
         pool_k, training = meta["pool_k"], meta["training"]
+        # row segments (whole-tree execution): per-mini-batch BatchNorm statistics inside one chain call
+        seg_ptr, seg_keep = _hip.segments_arg(meta.get("seg_off") if training else None)
+        nseg = 1 if seg_ptr is None else len(meta["seg_off"]) - 1
         dev = x.device
         arr = (_hip.MLPLayer * n)()
         ys, stats = [], []
@@ -79,7 +82,7 @@ class _ChainFn(torch.autograd.Function):
                 y = None                                          # the chain writes `out` directly
             else:
                 y = torch.empty(rows, cout, dtype=torch.float32, device=dev)
-            st = torch.empty(8, cout, dtype=torch.float32, device=dev) if spec["has_bn"] else None
+            st = torch.empty(8 * nseg, cout, dtype=torch.float32, device=dev) if spec["has_bn"] else None
             L.y, L.stats = _hip.ptr(y), _hip.ptr(st)
             ys.append(y)
             stats.append(st)
@@ -91,13 +94,14 @@ class _ChainFn(torch.autograd.Function):
         else:
             out = torch.empty(rows, cout_last, dtype=torch.float32, device=dev)
             arg = None
-        ws = torch.empty(lib.pn2_mlp_workspace_bytes(rows, arr, n), dtype=torch.uint8, device=dev)
+        ws = torch.empty(lib.pn2_mlp_workspace_bytes(rows, arr, n, nseg), dtype=torch.uint8, device=dev)
         flops = 2 * rows * sum(int(a.cin) * int(a.cout) for a in arr)
         nbytes = 4 * rows * (cin0 + 2 * sum(int(a.cout) for a in arr))
         _hip.call("mlp_chain_fwd", lib.pn2_mlp_chain_fwd_f32, x.data_ptr(), x.stride(0), rows, arr, n, int(training),
-                  int(pool_k), out.data_ptr(), _hip.ptr(arg), ws.data_ptr(), ws.numel(), _hip.stream_ptr(),
+                  int(pool_k), out.data_ptr(), _hip.ptr(arg), seg_ptr, ws.data_ptr(), ws.numel(), _hip.stream_ptr(),
                   nbytes=nbytes, flops=flops)
         ctx.meta = meta
+        ctx.nseg = nseg
         ctx.arr = arr
         ctx.dims = (rows, cin0)
         ctx.save_for_backward(x, arg, *[t for t in ys if t is not None], *[t for t in stats if t is not None], *params)
@@ -152,18 +156,22 @@ class _ChainFn(torch.autograd.Function):
         dx = torch.empty(rows, cin0, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
         sa = torch.empty(rows * maxc, dtype=torch.float32, device=dev)
         sb = torch.empty(rows * maxc, dtype=torch.float32, device=dev)
-        ws = torch.empty(lib.pn2_mlp_workspace_bytes(rows, arr, n), dtype=torch.uint8, device=dev)
+        seg_ptr, seg_keep = _hip.segments_arg(meta.get("seg_off") if ctx.nseg > 1 else None)
+        ws = torch.empty(lib.pn2_mlp_workspace_bytes(rows, arr, n, ctx.nseg), dtype=torch.uint8, device=dev)
         flops = 4 * rows * sum(int(a.cin) * int(a.cout) for a in arr)
         nbytes = 4 * rows * (cin0 + 5 * sum(int(a.cout) for a in arr))
         _hip.call("mlp_chain_bwd", lib.pn2_mlp_chain_bwd_f32, x.data_ptr(), x.stride(0), rows, arr, n, int(meta["pool_k"]),
-                  dout.data_ptr(), _hip.ptr(arg), _hip.ptr(dx), cin0, sa.data_ptr(), sb.data_ptr(), ws.data_ptr(), ws.numel(),
-                  _hip.stream_ptr(), nbytes=nbytes, flops=flops)
+                  dout.data_ptr(), _hip.ptr(arg), _hip.ptr(dx), cin0, sa.data_ptr(), sb.data_ptr(), seg_ptr, ws.data_ptr(),
+                  ws.numel(), _hip.stream_ptr(), nbytes=nbytes, flops=flops)
         return (dx, None, *grads)
 
 
-def chain_rows(x, layers, pool_k=1):
+def chain_rows(x, layers, pool_k=1, seg_off=None):
     """x [R, C_in] fp32 rows; layers: iterable of (conv, bn_or_None, relu: bool).
-    -> [R, C_out], or [R // pool_k, C_out] (max over each group of pool_k consecutive rows) when pool_k > 1."""
+    -> [R, C_out], or [R // pool_k, C_out] (max over each group of pool_k consecutive rows) when pool_k > 1.
+    seg_off: optional ascending row offsets [0, ..., R] of the mini-batches the rows are made of (whole-tree execution):
+    train-mode BatchNorm then works per segment, exactly as if the segments had been separate calls, and every layer's
+    running statistics / num_batches_tracked advance once per segment."""
     layers = list(layers)
     if not layers:
         return x
@@ -187,6 +195,14 @@ def chain_rows(x, layers, pool_k=1):
         specs.append(spec)
     # a chain is either all batch statistics or all running statistics (module.train()/eval() sets them together)
     meta = {"layers": specs, "pool_k": int(pool_k), "training": training}
+    nseg = 1
+    if seg_off is not None and len(seg_off) > 2 and training:
+        if any(bn is not None and bn.momentum is None for _, bn, _ in layers):
+            raise NotImplementedError("row segments with cumulative-average BatchNorm (momentum=None)")
+        if len(seg_off) - 1 > _hip.MAX_SEGMENTS:
+            raise RuntimeError(f"chain_rows: at most {_hip.MAX_SEGMENTS} row segments per call, got {len(seg_off) - 1}")
+        meta["seg_off"] = [int(v) for v in seg_off]
+        nseg = len(seg_off) - 1
     if bump:
-        torch._foreach_add_(bump, 1)
+        torch._foreach_add_(bump, nseg if training else 1)
     return _ChainFn.apply(x, meta, *params)

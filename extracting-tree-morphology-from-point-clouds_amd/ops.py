@@ -251,3 +251,109 @@ class ThreeInterpolateConcat(torch.autograd.Function):
                       idx32.data_ptr(), w.data_ptr(), B, N, S, D2, d2.data_ptr(), ws.data_ptr(), ws.numel(), _hip.stream_ptr(),
                       nbytes=B * N * (3 * 12 + 4 * D2) + 4 * B * S * D2)
         return d1, d2, None, None
+
+
+# ------------------------------------------------------------------------------- ragged clouds (whole-tree execution)
+class RaggedClouds:
+    """Level-0 input of a whole tree: C clouds of different lengths in flat CHANNEL-FIRST buffers (include/pn2_hip.h,
+    "Ragged clouds") -- the reference's per-mini-batch tensors [B_j, CH, N_j] laid end to end, no transposition.
+    xyz_cf: float32 [3 * rows]; feats_cf: float32 [D * rows] or None; lengths: host list of C ints."""
+
+    def __init__(self, xyz_cf, feats_cf, dim_feat, lengths):
+        self.xyz_cf, self.feats_cf, self.D = xyz_cf, feats_cf, int(dim_feat) if feats_cf is not None else 0
+        self.lengths = [int(n) for n in lengths]
+        self.C, self.n_max, self.n_min = len(self.lengths), max(self.lengths), min(self.lengths)
+        off = [0]
+        for n in self.lengths:
+            off.append(off[-1] + n)
+        self.rows = off[-1]
+        if self.rows >= 2 ** 31 // 4:
+            raise RuntimeError("RaggedClouds: too many points for one pass")
+        self.coff_host = off
+        self.coff = torch.tensor(off, dtype=torch.int32).to(xyz_cf.device, non_blocking=True)
+
+
+def fps_ragged(rc, npoint, start):
+    """-> (idx int32 [C,npoint] cloud-local, new_xyz [C,npoint,3]); same samples as per-cloud farthest_point_sample."""
+    lib = _hip.lib()
+    dev = rc.xyz_cf.device
+    idx = torch.empty(rc.C, npoint, dtype=torch.int32, device=dev)
+    new_xyz = torch.empty(rc.C, npoint, 3, dtype=torch.float32, device=dev)
+    nbytes = lib.pn2_fps_ragged_workspace_bytes(rc.C, rc.n_max, npoint)
+    if nbytes == 0:
+        raise RuntimeError(f"fps_ragged: unsupported size (longest cloud {rc.n_max} > 16384?)")
+    ws = _workspace(nbytes, dev)      # single-workgroup clouds: no hand-off, the error word is never touched
+    start = start.to(device=dev, dtype=torch.int64).contiguous()
+    _hip.call("farthest_point_sample", lib.pn2_fps_ragged_f32, rc.xyz_cf.data_ptr(), rc.coff.data_ptr(), rc.C, rc.n_max,
+              npoint, start.data_ptr(), idx.data_ptr(), new_xyz.data_ptr(), ws.data_ptr(), ws.numel(), _hip.stream_ptr(),
+              nbytes=12 * rc.rows + 8 * rc.C * npoint)
+    return idx, new_xyz
+
+
+def ball_query_ragged(radius, nsample, rc, new_xyz):
+    """-> int32 [C,S,nsample] cloud-local indices; every cloud must hold at least nsample points."""
+    if rc.n_min < nsample:
+        raise RuntimeError("ball_query_ragged needs every cloud to hold at least nsample points")
+    new_xyz = new_xyz.contiguous()
+    S = new_xyz.shape[1]
+    out = torch.empty(rc.C, S, int(nsample), dtype=torch.int32, device=new_xyz.device)
+    r2 = ctypes.c_float(float(radius) ** 2).value
+    _hip.call("query_ball_point", _hip.lib().pn2_ball_query_ragged_f32, rc.xyz_cf.data_ptr(), rc.coff.data_ptr(),
+              new_xyz.data_ptr(), rc.C, rc.n_max, S, r2, int(nsample), out.data_ptr(), _hip.stream_ptr(),
+              nbytes=12 * rc.rows + rc.C * (12 * S + 8 * S * int(nsample)))
+    return out
+
+
+def group_ragged(rc, new_xyz, idx, xyz_last=False):
+    """sample_and_group's gather + centre + concat on ragged level-0 clouds -> [C,S,K,3+D].  The level-0 inputs are
+    data (no gradient flows into them), so this is a plain function."""
+    new_xyz = new_xyz.contiguous()
+    _, S, K = idx.shape
+    out = torch.empty(rc.C, S, K, 3 + rc.D, dtype=torch.float32, device=new_xyz.device)
+    _hip.call("group_points", _hip.lib().pn2_group_ragged_f32, rc.xyz_cf.data_ptr(), _hip.ptr(rc.feats_cf), rc.D,
+              rc.coff.data_ptr(), new_xyz.data_ptr(), idx.data_ptr(), rc.C, S, K, int(bool(xyz_last)), out.data_ptr(),
+              status_word(new_xyz.device).data_ptr(), _hip.stream_ptr(), nbytes=rc.C * S * K * (8 + 8 * (3 + rc.D)))
+    return out
+
+
+def three_nn_ragged(rc, xyz2):
+    """dense side = the ragged level-0 clouds, sampled side xyz2 [C,S,3] -> (idx int32 [rows,3], weight [rows,3])."""
+    xyz2 = xyz2.contiguous()
+    S = xyz2.shape[1]
+    if S < 3:
+        raise RuntimeError(f"three_nn needs at least 3 sampled points, got {S}")
+    idx = torch.empty(rc.rows, 3, dtype=torch.int32, device=xyz2.device)
+    w = torch.empty(rc.rows, 3, dtype=torch.float32, device=xyz2.device)
+    _hip.call("three_nn", _hip.lib().pn2_three_nn_ragged_f32, rc.xyz_cf.data_ptr(), rc.coff.data_ptr(), xyz2.data_ptr(), rc.C,
+              rc.n_max, S, idx.data_ptr(), w.data_ptr(), _hip.stream_ptr(), nbytes=48 * rc.rows + 12 * rc.C * S)
+    return idx, w
+
+
+class ThreeInterpolateRagged(torch.autograd.Function):
+    """points2 [C,S,D] -> packed rows [rows, D] = sum_k w_k * points2[cloud(row), idx_k]  (blocks.py:204 on ragged
+    clouds; there is no skip connection at level 0: fp1 is called with points1 = None, PointNet2.py:156)."""
+
+    @staticmethod
+    def forward(ctx, points2, idx, w, rc):
+        points2 = _hip.f32(points2).contiguous()
+        C, S, D = points2.shape
+        out = torch.empty(rc.rows, D, dtype=torch.float32, device=points2.device)
+        _hip.call("three_interpolate", _hip.lib().pn2_three_interpolate_ragged_f32, points2.data_ptr(), idx.data_ptr(),
+                  w.data_ptr(), rc.coff.data_ptr(), C, rc.n_max, rc.rows, S, D, out.data_ptr(), D, 0,
+                  status_word(points2.device).data_ptr(), _hip.stream_ptr(), nbytes=rc.rows * (36 + 4 * D) + 4 * C * S * D)
+        ctx.save_for_backward(idx, w)
+        ctx.rc, ctx.dims = rc, (C, S, D)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        idx, w = ctx.saved_tensors
+        rc, (C, S, D) = ctx.rc, ctx.dims
+        dout = dout.contiguous()
+        d2 = torch.empty(C, S, D, dtype=torch.float32, device=dout.device)
+        lib = _hip.lib()
+        ws = _workspace(lib.pn2_three_interpolate_grad_ragged_workspace_bytes(C, rc.rows, S), dout.device)
+        _hip.call("three_interpolate_grad", lib.pn2_three_interpolate_grad_ragged_f32, dout.data_ptr(), D, 0, idx.data_ptr(),
+                  w.data_ptr(), rc.coff.data_ptr(), C, rc.n_max, rc.rows, S, D, d2.data_ptr(), ws.data_ptr(), ws.numel(),
+                  _hip.stream_ptr(), nbytes=rc.rows * (36 + 4 * D) + 4 * C * S * D)
+        return d2, None, None, None

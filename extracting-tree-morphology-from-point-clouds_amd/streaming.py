@@ -1,0 +1,271 @@
+"""Whole-tree execution of the reference's raster modes (Modules/PointNet2/PointNet2.py:210-394).
+
+The reference feeds a tree to the network as a stream of mini-batches of rasters -- ~40 forward (+ backward) passes of
+~10 small zero-padded clouds each for a 262 144-point tree -- and every pass is ~460 kernel launches a few microseconds
+long: on a 256-CU GPU that is launch latency, not work.  Nothing couples the passes except (a) the weights, which do not
+change inside a tree (one optimizer step per tree, train_utils.py:57-61), (b) the BatchNorm running statistics and (c) the
+global CPU RNG that draws the FPS start indices.  So all mini-batches of a tree are run here as ONE pass over a ragged
+super-batch:
+
+  * level 0 keeps every raster at its mini-batch's padded length (padding is real data to FPS / ball query / BatchNorm,
+    SURVEY Q1): the per-mini-batch tensors are laid end to end in flat channel-first buffers (ops.RaggedClouds) and the
+    level-0 kernels index them through per-cloud offsets; sampled levels are regular [C, S, *] batches of all C rasters;
+  * every MLP chain runs once over all rows with the mini-batches as row SEGMENTS: train-mode BatchNorm statistics,
+    normalisation and backward are per segment, running statistics advance segment after segment (mlp.chain_rows);
+  * FPS start indices are drawn up front in the reference's order (per mini-batch: sa1, sa2, ... -- one torch.randint
+    each, pointnet2_utils.py:79), so a seeded run samples the same centroids;
+  * the per-mini-batch losses are segment means of one per-row loss tensor, their sum is back-propagated once
+    (= the sum of the reference's per-mini-batch backward calls), predictions are scatter-averaged per point id with
+    index_add (no boolean indexing, no host synchronisation before the final loss read-back).
+
+Same numbers as the sequential loop up to fp32 summation order (tests/test_streaming.py compares both with the
+reference's fixture).  Deviation, documented: when one point id occurs twice inside ONE mini-batch (overlapping rasters,
+stride < size), the reference's `sum[ids] += x` keeps an arbitrary one of the duplicates; here both are averaged.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import _hip, ops
+from .mlp import chain_rows
+from .PointNet2.blocks import PointNetSetAbstractionMsg, _group_mlp_max
+
+MAX_ROWS_PER_PASS = 6_000_000       # level-0 rows (padded points) per pass: ~60 GB of activations at depth 5
+
+
+class TreeLayout:
+    """Host-side description of one pass: which mini-batches, how many rasters each, their padded lengths."""
+
+    def __init__(self, mini_batches):
+        self.mbs = mini_batches
+        self.clouds = [int(mb["coords"].shape[0]) for mb in mini_batches]            # B_j
+        self.length = [int(mb["coords"].shape[2]) for mb in mini_batches]            # N_j
+        self.n_valid = [int(mb["point_ids"].shape[0]) for mb in mini_batches]
+        self.M = len(mini_batches)
+        self.cum_clouds = np.concatenate([[0], np.cumsum(self.clouds)]).astype(np.int64)
+        self.C = int(self.cum_clouds[-1])
+        self.rows0 = np.concatenate([[0], np.cumsum(np.multiply(self.clouds, self.length))]).astype(np.int64)
+
+    def seg_rows(self, rows_per_cloud):
+        """row offsets of the segments for a regular level with `rows_per_cloud` rows per raster"""
+        return (self.cum_clouds * int(rows_per_cloud)).tolist()
+
+
+def supported(mini_batches, model):
+    """The fused path needs: every padded raster at least as long as the first level's neighbourhood size (so that
+    K = nsample everywhere), no longer than one FPS workgroup holds, and at most MAX_SEGMENTS mini-batches per pass
+    (longer streams are cut into several passes by the caller)."""
+    sa1 = model.sa1
+    k1 = max(sa1.nsample_list) if isinstance(sa1, PointNetSetAbstractionMsg) else sa1.nsample
+    for mb in mini_batches:
+        n = int(mb["coords"].shape[2])
+        if n < max(k1, 3) or n > 16384 or mb["coords"].shape[0] < 1:
+            return False
+    return len(mini_batches) > 0
+
+
+def _device_cat(tensors, device, dtype=None):
+    """cat on whichever side the pieces live, one upload if they are host tensors (the reference's collate output)."""
+    t = torch.cat([x.reshape(-1) for x in tensors])
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    return t.to(device, non_blocking=True)
+
+
+def draw_starts(layout, model):
+    """FPS start indices for every SA level, drawn in the reference's order: mini-batch after mini-batch, level after
+    level (each SA forward consumes one torch.randint from the global CPU generator, pointnet2_utils.py:79)."""
+    sas = _sa_modules(model)
+    per_level = [[] for _ in sas]
+    for b, n in zip(layout.clouds, layout.length):
+        upper = n
+        for lvl, sa in enumerate(sas):
+            per_level[lvl].append(torch.randint(0, upper, (b,), dtype=torch.long))
+            upper = sa.npoint
+    return [torch.cat(p) for p in per_level]
+
+
+def _sa_modules(model):
+    out, lvl = [], 1
+    while hasattr(model, f"sa{lvl}"):
+        out.append(getattr(model, f"sa{lvl}"))
+        lvl += 1
+    return out
+
+
+def _sa_level(sa, xyz_t, pts_t, start, layout, rc=None):
+    """One set-abstraction level over all rasters of the pass.  rc: ragged level-0 clouds (first level) or None
+    (xyz_t [C,N,3], pts_t [C,N,D] regular).  -> new_xyz [C,S,3], pooled [C,S,C_out] (channels-last)."""
+    dev = start.device
+    if rc is not None:
+        fps_idx, new_xyz = ops.fps_ragged(rc, sa.npoint, start)
+    else:
+        fps_idx, new_xyz = ops.furthest_point_sample(xyz_t, sa.npoint, start)
+    msg = isinstance(sa, PointNetSetAbstractionMsg)
+    specs = list(zip(sa.radius_list, sa.nsample_list, sa.conv_blocks, sa.bn_blocks)) if msg else \
+        [(sa.radius, sa.nsample, sa.mlp_convs, sa.mlp_bns)]
+    outs = []
+    for radius, K, convs, bns in specs:
+        if rc is not None:
+            idx = ops.ball_query_ragged(radius, K, rc, new_xyz)
+            grouped = ops.group_ragged(rc, new_xyz, idx, xyz_last=msg)
+        else:
+            idx = ops.ball_query(radius, K, xyz_t, new_xyz)
+            grouped = ops.GroupPoints.apply(xyz_t, new_xyz, pts_t, idx, msg)
+        rows_per_cloud = grouped.shape[1] * grouped.shape[2]
+        outs.append(_group_mlp_max(grouped, convs, bns, seg_off=layout.seg_rows(rows_per_cloud)))
+    return new_xyz, (outs[0] if len(outs) == 1 else torch.cat(outs, dim=-1))
+
+
+def _fp_level(fp, x1, x2, p1, p2, layout, rc=None):
+    """One feature-propagation level.  rc given: the dense side is the ragged level 0 (x1, p1 unused) and the result is
+    packed rows [rows, C_out]; otherwise x1 [C,N,3], p1 [C,N,D1] or None -> [C,N,C_out]."""
+    layers = [(c, b, True) for c, b in zip(fp.mlp_convs, fp.mlp_bns)]
+    C, S, _ = x2.shape
+    if rc is not None:
+        if S == 1:
+            raise RuntimeError("feature propagation from a single sampled point onto ragged clouds is not supported")
+        idx, w = ops.three_nn_ragged(rc, x2)
+        feats = ops.ThreeInterpolateRagged.apply(p2, idx, w, rc)
+        return chain_rows(feats, layers, seg_off=layout.rows0.tolist())
+    N = x1.shape[1]
+    if S == 1:
+        feats = p2.repeat(1, N, 1)
+        if p1 is not None:
+            feats = torch.cat([p1, feats], dim=-1)
+    else:
+        idx, w = ops.three_nn(x1, x2)
+        feats = ops.ThreeInterpolateConcat.apply(p1, p2, idx, w)
+    y = chain_rows(feats.reshape(C * N, -1), layers, seg_off=layout.seg_rows(N))
+    return y.view(C, N, -1)
+
+
+def backbone_and_heads(model, layout, device):
+    """-> (semantic logits [rows,2], offsets [rows,3]) for the packed padded rows of the pass (row = raster by raster,
+    point by point, i.e. the order of `masks_pad.reshape(-1)` mini-batch after mini-batch)."""
+    mbs = layout.mbs
+    lengths = np.repeat(layout.length, layout.clouds).tolist()
+    xyz_cf = _device_cat([mb["coords"] for mb in mbs], device, torch.float32)
+    feats_cf, dim_feat = None, 0
+    if model.use_features:
+        dim_feat = int(mbs[0]["feats"].shape[1])
+        feats_cf = _device_cat([mb["feats"] for mb in mbs], device, torch.float32)
+    rc = ops.RaggedClouds(xyz_cf, feats_cf, dim_feat, lengths)
+    starts = [s.pin_memory().to(device, non_blocking=True) for s in draw_starts(layout, model)]
+    sas = _sa_modules(model)
+    n = len(sas)
+    with torch.amp.autocast("cuda", enabled=False):
+        xyz, pts = [None], [None]
+        for lvl, sa in enumerate(sas):
+            nx, npts = _sa_level(sa, xyz[-1], pts[-1], starts[lvl], layout, rc=rc if lvl == 0 else None)
+            xyz.append(nx)
+            pts.append(npts)
+        for level in range(n, 1, -1):
+            pts[level - 1] = _fp_level(getattr(model, f"fp{level}"), xyz[level - 1], xyz[level], pts[level - 1], pts[level],
+                                       layout)
+        feats = _fp_level(model.fp1, None, xyz[1], None, pts[1], layout, rc=rc)
+        seg0 = layout.rows0.tolist()
+        sem = chain_rows(feats, model.semantic_linear._layers(), seg_off=seg0)
+        off = chain_rows(feats, model.offset_linear._layers(), seg_off=seg0)
+    return sem, off
+
+
+def _valid_rows(layout, device):
+    """Packed row index of every real point (the reference's x[masks_pad], mini-batch after mini-batch) -- the count
+    is known on the host (point_ids), so no synchronisation -- plus the global point id, the offset mask and the
+    mini-batch number of each."""
+    pad = _device_cat([mb["masks_pad"] for mb in layout.mbs], device)
+    n_valid = int(sum(layout.n_valid))
+    rows = torch.nonzero_static(pad, size=n_valid).squeeze(1) if hasattr(torch, "nonzero_static") else pad.nonzero().squeeze(1)
+    ids = _device_cat([mb["point_ids"] for mb in layout.mbs], device, torch.long)
+    moff = _device_cat([mb["masks_off"] for mb in layout.mbs], device)
+    counts = torch.tensor(layout.n_valid).to(device, non_blocking=True)
+    seg = torch.repeat_interleave(torch.arange(layout.M, device=device), counts, output_size=n_valid)   # no sync
+    return rows, ids, moff, seg
+
+
+class _Accumulators:
+    def __init__(self, n, device):
+        self.sem = torch.zeros(n, 2, dtype=torch.float, device=device)
+        self.off = torch.zeros(n, 3, dtype=torch.float, device=device)
+        self.sem_cnt = torch.zeros(n, 1, dtype=torch.float, device=device)
+        self.off_cnt = torch.zeros(n, 1, dtype=torch.float, device=device)
+
+    def add(self, ids, sem, off, moff, differentiable):
+        m = moff.to(torch.float).unsqueeze(1)
+        if differentiable:                  # forward_hierarchical keeps autograd history through the average
+            self.sem = self.sem.index_add(0, ids, sem)
+            self.off = self.off.index_add(0, ids, off * m)
+        else:
+            self.sem.index_add_(0, ids, sem.detach())
+            self.off.index_add_(0, ids, off.detach() * m)
+        self.sem_cnt.index_add_(0, ids, torch.ones_like(m))
+        self.off_cnt.index_add_(0, ids, m)
+
+    def average(self):
+        return {"semantic_prediction_logits": self.sem / self.sem_cnt.clamp_min(1.0),
+                "offset_predictions": self.off / self.off_cnt.clamp_min(1.0)}
+
+
+def _passes(mini_batches):
+    """cut a stream into passes of at most MAX_SEGMENTS mini-batches and MAX_ROWS_PER_PASS padded points"""
+    cur, rows = [], 0
+    for mb in mini_batches:
+        r = int(mb["coords"].shape[0]) * int(mb["coords"].shape[2])
+        if cur and (len(cur) == _hip.MAX_SEGMENTS or rows + r > MAX_ROWS_PER_PASS):
+            yield cur
+            cur, rows = [], 0
+        cur.append(mb)
+        rows += r
+    if cur:
+        yield cur
+
+
+def run_tree(model, batch, return_loss, scaler=None, streaming=True):
+    """The fused counterpart of PointNet2.forward_hierarchical_streaming (streaming=True: per-mini-batch losses,
+    back-propagated here, scaled by 50 through `scaler`) and forward_hierarchical (streaming=False: one loss on the
+    averaged predictions, returned with its autograd history).  `batch["mini_batches"]` must be a list accepted by
+    `supported`."""
+    device = torch.device("cuda", torch.cuda.current_device())
+    acc = _Accumulators(batch["cloud_length"], device)
+    want_stream_loss = return_loss and streaming
+    if want_stream_loss:
+        sem_all = batch["semantic_labels"].squeeze().to(device, non_blocking=True)
+        off_all = batch["offset_labels"].to(device, non_blocking=True)
+        total = torch.zeros((), dtype=torch.float64, device=device)
+        sums = torch.zeros(2, dtype=torch.float32, device=device)
+    n_mb = 0
+    for chunk in _passes(batch["mini_batches"]):
+        layout = TreeLayout(chunk)
+        sem_rows, off_rows = backbone_and_heads(model, layout, device)
+        rows, ids, moff, seg = _valid_rows(layout, device)
+        sem, off = sem_rows.index_select(0, rows), off_rows.index_select(0, rows)
+        acc.add(ids, sem, off, moff, differentiable=return_loss and not streaming)
+        if want_stream_loss:
+            # per-mini-batch point_wise_loss (Loss.py:6-36) as segment means of per-row terms
+            M = layout.M
+            m = moff.to(torch.float32)
+            ce = F.cross_entropy(sem.float(), sem_all.index_select(0, ids), reduction="none")
+            dist = torch.sqrt(torch.clamp((off.float() - off_all.index_select(0, ids)).pow(2).sum(1), min=1e-8)) * m
+            n_sem = torch.tensor(layout.n_valid, dtype=torch.float32).to(device, non_blocking=True)
+            sem_loss = torch.zeros(M, device=device).index_add(0, seg, ce) / n_sem.clamp_min(1.0)
+            n_off = torch.zeros(M, device=device).index_add_(0, seg, m)
+            off_loss = torch.zeros(M, device=device).index_add(0, seg, dist) / n_off.clamp_min(1.0)
+            sem_loss, off_loss = sem_loss * model.loss_multiplier_semantic, off_loss * model.loss_multiplier_offset
+            mini = sem_loss + off_loss
+            if scaler:
+                scaler.scale(mini.sum() * 50).backward()        # = the reference's per-mini-batch backward calls, summed
+            total += mini.detach().double().sum()
+            sums += torch.stack([sem_loss.detach().sum(), off_loss.detach().sum()])
+            del sem_loss, off_loss, mini, ce, dist
+        n_mb += layout.M
+        del sem_rows, off_rows, sem, off
+    output = acc.average()
+    if not return_loss:
+        return output
+    if not streaming:
+        return model.get_loss_hierarchical(output, batch["semantic_labels"].squeeze(), batch["offset_labels"])
+    total_loss = float(total)                 # the one host synchronisation of the tree
+    ops.check_status(device)
+    loss_dict = {"semantic_loss": sums[0] / max(n_mb, 1), "offset_loss": sums[1] / max(n_mb, 1)}
+    return (total_loss / n_mb if n_mb else 0.0), loss_dict

@@ -177,6 +177,38 @@ int pn2_three_interpolate_grad_f32(const float *dout, int64_t out_stride, int64_
                                    float *dpoints2, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * Ragged clouds (whole-tree execution of the reference's streaming mode, Modules/PointNet2/PointNet2.py:210-327).
+ *   All mini-batches of a tree are processed by ONE set of launches.  Mini-batch j holds B_j rasters zero-padded to N_j
+ *   points (RasterizedTreeSet.py:407-429), so the level-0 clouds have different lengths: cloud b has
+ *   n_b = coff[b+1] - coff[b] points (coff: device int32 [C+1], coff[0] = 0), and the level-0 tensors are the reference's
+ *   per-mini-batch channel-first tensors [B_j, CH, N_j] laid end to end in one flat buffer: element (b, i, ch) lives at
+ *   CH * coff[b] + ch * n_b + i.  Sampled levels are regular [C, S, *].  Per-point results (three_nn indices / weights,
+ *   interpolated rows) are PACKED rows, row = coff[b] + i, rows = coff[C].  n_max = the longest cloud.  Results are
+ *   bit-identical to calling the regular entry points mini-batch by mini-batch.
+ *   pn2_fps_ragged_f32: every cloud <= 16384 points (one workgroup per cloud); start [C]; out_idx [C,npoint] cloud-local.
+ *   pn2_ball_query_ragged_f32: every cloud must hold at least nsample points (Keff = nsample); out_idx [C,S,nsample].
+ *   pn2_group_ragged_f32: xyz_cf (3 planes) and feats_cf (D planes) flat; out [C,S,K,3+D] as pn2_group_f32.
+ *   pn2_three_nn_ragged_f32 / pn2_three_interpolate_ragged_f32 / _grad: FP level 0 (dense side ragged, S >= 3).
+ */
+size_t pn2_fps_ragged_workspace_bytes(int C, int n_max, int npoint);
+int pn2_fps_ragged_f32(const float *xyz_cf, const int32_t *coff, int C, int n_max, int npoint, const int64_t *start,
+                       int32_t *out_idx, float *out_xyz, void *workspace, size_t workspace_bytes, void *stream);
+int pn2_ball_query_ragged_f32(const float *xyz_cf, const int32_t *coff, const float *new_xyz, int C, int n_max, int S,
+                              float r2, int nsample, int32_t *out_idx, void *stream);
+int pn2_group_ragged_f32(const float *xyz_cf, const float *feats_cf, int D, const int32_t *coff, const float *new_xyz,
+                         const int32_t *idx, int C, int S, int K, int xyz_last, float *out, int32_t *status,
+                         void *stream);
+int pn2_three_nn_ragged_f32(const float *xyz1_cf, const int32_t *coff, const float *xyz2, int C, int n_max, int S,
+                            int32_t *out_idx, float *out_w, void *stream);
+int pn2_three_interpolate_ragged_f32(const float *points2, const int32_t *idx, const float *w, const int32_t *coff, int C,
+                                     int n_max, long long rows, int S, int D, float *out, int64_t out_stride,
+                                     int64_t out_offset, int32_t *status, void *stream);
+size_t pn2_three_interpolate_grad_ragged_workspace_bytes(int C, long long rows, int S);
+int pn2_three_interpolate_grad_ragged_f32(const float *dout, int64_t out_stride, int64_t out_offset, const int32_t *idx,
+                                          const float *w, const int32_t *coff, int C, int n_max, long long rows, int S,
+                                          int D, float *dpoints2, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * Pointwise MLP chains: (1x1 conv -> BatchNorm -> ReLU) x n [-> max over groups of pool_k rows]
  *   replaces the Conv2d/BatchNorm2d/ReLU/max stack of Modules/PointNet2/blocks.py:93-98 (set abstraction),
  *   the Conv1d/BatchNorm1d/ReLU stack of :213-215 (feature propagation) and ConvHead :7-35, fwd and bwd.
@@ -189,13 +221,13 @@ int pn2_three_interpolate_grad_f32(const float *dout, int64_t out_stride, int64_
  *   pool_k <= 1: out [rows][cout_last] = act_last        (a last layer without BatchNorm writes y itself)
  *   pool_k  > 1: out [rows/pool_k][cout_last] = max over each group of pool_k consecutive rows, pool_arg
  *                [rows/pool_k][cout_last] int32 = first row offset attaining it (torch.max's choice).
- * stats: [8][cout] floats per BatchNorm layer (mean, biased var, invstd, gamma*invstd, beta, and two rows
+ * stats: [8][cout] floats per BatchNorm layer ([nseg][8][cout] with row segments, see below) (mean, biased var, invstd, gamma*invstd, beta, and two rows
  * written by the backward pass); running_mean/var may be NULL (no tracking).
  *
  * Backward: dout has the shape of out; gradients are ACCUMULATED (+=) into dweight/dbias/dgamma/dbeta where
  * non-NULL (dbias of a conv feeding a BatchNorm is analytically zero and is left untouched); dx [rows][cin_0]
  * (row stride lddx) is written when non-NULL.  scratch_a/b: two buffers of rows * max(cin_i, cout_last) floats.
- * workspace: pn2_mlp_workspace_bytes(rows, layers, nlayers) bytes for either direction.
+ * workspace: pn2_mlp_workspace_bytes(rows, layers, nlayers, nseg) bytes for either direction.
  */
 typedef struct pn2_mlp_layer {
     int32_t cin, cout;
@@ -210,14 +242,28 @@ typedef struct pn2_mlp_layer {
     float *dweight, *dbias, *dgamma, *dbeta;
 } pn2_mlp_layer;
 
-size_t pn2_mlp_workspace_bytes(int rows, const pn2_mlp_layer *layers, int nlayers);
+/* Row segments (whole-tree execution).  The reference's streaming mode runs the mini-batches of a tree one after the
+ * other (Modules/PointNet2/PointNet2.py:238-306): every mini-batch is a forward pass of its own, with its OWN train-mode
+ * BatchNorm statistics and one momentum update of the running statistics.  With `segments` the rows of a chain are the
+ * concatenation of nseg such mini-batches: statistics, normalisation and the BatchNorm backward are per segment, the
+ * running statistics are updated segment after segment, weight gradients are summed over all rows -- the same numbers as
+ * nseg separate calls, in one set of launches.  Per-layer `stats` blocks then hold [nseg][8][cout] floats.
+ * row_off is a HOST array of nseg + 1 ascending row offsets (row_off[0] = 0, row_off[nseg] = rows; every segment a
+ * multiple of pool_k rows); it is read during the call only.  NULL or nseg <= 1: one segment.  Eval mode ignores it. */
+#define PN2_MAX_SEGMENTS 128
+typedef struct pn2_segments {
+    int32_t nseg;
+    const int32_t *row_off;
+} pn2_segments;
+
+size_t pn2_mlp_workspace_bytes(int rows, const pn2_mlp_layer *layers, int nlayers, int nseg);
 int pn2_mlp_chain_fwd_f32(const float *x, int64_t ldx, int rows, const pn2_mlp_layer *layers, int nlayers,
-                          int training, int pool_k, float *out, int32_t *pool_arg, void *workspace,
-                          size_t workspace_bytes, void *stream);
+                          int training, int pool_k, float *out, int32_t *pool_arg, const pn2_segments *segments,
+                          void *workspace, size_t workspace_bytes, void *stream);
 int pn2_mlp_chain_bwd_f32(const float *x, int64_t ldx, int rows, const pn2_mlp_layer *layers, int nlayers,
                           int pool_k, const float *dout, const int32_t *pool_arg, float *dx, int64_t lddx,
-                          float *scratch_a, float *scratch_b, void *workspace, size_t workspace_bytes,
-                          void *stream);
+                          float *scratch_a, float *scratch_b, const pn2_segments *segments, void *workspace,
+                          size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Measurement hook (bench.py): with profiling enabled every kernel launch of the library is bracketed by two

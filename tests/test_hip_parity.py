@@ -456,10 +456,13 @@ class _FakeScaler:
         return x
 
 
-def test_forward_hierarchical_streaming_golden(pn2):
+@pytest.mark.parametrize("mode", ["fused", "sequential"])
+def test_forward_hierarchical_streaming_golden(pn2, mode, monkeypatch):
     """PointNet2.forward_hierarchical_streaming (reference PointNet2.py:210-327) on a 6-raster tree in mini-batches of
     two: per-mini-batch backward with gradient accumulation, scatter-averaged predictions per original point id.
-    The fixture was produced by the reference's own loop (tests/golden/make_golden.py:make_streaming)."""
+    The fixture was produced by the reference's own loop (tests/golden/make_golden.py:make_streaming).  Both execution
+    modes: the whole-tree pass with per-mini-batch BatchNorm segments (default) and the mini-batch-by-mini-batch loop."""
+    monkeypatch.setenv("PN2_STREAMING", mode)
     from pn2_amd.PointNet2.PointNet2 import PointNet2
     from pn2_amd.synthetic import gaussian_branch_tree, rasterize
     g = gold("streaming_d5.npz")

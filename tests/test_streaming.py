@@ -1,0 +1,280 @@
+"""GPU: whole-tree execution (streaming.py) -- the ragged level-0 kernels and the segmented MLP chains against their
+mini-batch-by-mini-batch counterparts (bit-exact for indices, fp32 rounding for the chains), against the C oracle, and the
+fused streaming mode against the sequential loop on a synthetic tree.  The reference's own fixture for the mode is checked
+in tests/test_hip_parity.py::test_forward_hierarchical_streaming_golden (both modes)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import helpers
+from oracle import pn2_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pn2():
+    O.build()
+    return helpers.load_pkg()
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _ragged_batch(sizes, seed=0, dim_feat=4):
+    """mini-batches of rasters: sizes = [(B_j, N_j), ...]; every raster zero padded from a random real length"""
+    rng = np.random.default_rng(seed)
+    mbs = []
+    for b, n in sizes:
+        coords = np.zeros((b, 3, n), np.float32)
+        feats = np.zeros((b, dim_feat, n), np.float32)
+        for i in range(b):
+            real = int(rng.integers(max(3, n // 2), n + 1)) if i else n          # the first raster defines the padding
+            coords[i, :, :real] = (rng.normal(size=(3, real)) * 0.3 + rng.uniform(0, 20, size=(3, 1))).astype(np.float32)
+            feats[i, :, :real] = rng.normal(size=(dim_feat, real)).astype(np.float32)
+        mbs.append((coords, feats))
+    return mbs
+
+
+def _rc(pn2, mbs):
+    from pn2_amd import ops
+    xyz_cf = torch.cat([dev(c).reshape(-1) for c, _ in mbs])
+    feats_cf = torch.cat([dev(f).reshape(-1) for _, f in mbs])
+    lengths = [c.shape[2] for c, _ in mbs for _ in range(c.shape[0])]
+    return ops.RaggedClouds(xyz_cf, feats_cf, mbs[0][1].shape[1], lengths)
+
+
+def test_ragged_geometry_equals_per_minibatch_calls(pn2):
+    """FPS, ball query, grouping, three-NN and interpolation on ragged clouds: bit for bit what the regular entry points
+    return mini-batch by mini-batch (and therefore what the oracle returns)."""
+    from pn2_amd import ops
+    mbs = _ragged_batch([(3, 700), (2, 64), (4, 2500), (1, 33), (2, 9000)], seed=1)
+    rc = _rc(pn2, mbs)
+    S, K, r = 40, 32, 0.25
+    rng = np.random.default_rng(2)
+    starts = [rng.integers(0, c.shape[2], size=c.shape[0]) for c, _ in mbs]
+    idx, new_xyz = ops.fps_ragged(rc, S, dev(np.concatenate(starts)))
+    bq = ops.ball_query_ragged(r, K, rc, new_xyz)
+    grouped = ops.group_ragged(rc, new_xyz, bq)
+    nn_idx, nn_w = ops.three_nn_ragged(rc, new_xyz)
+    p2 = torch.randn(rc.C, S, 8, device="cuda", generator=torch.Generator("cuda").manual_seed(3)).requires_grad_(True)
+    interp = ops.ThreeInterpolateRagged.apply(p2, nn_idx, nn_w, rc)
+    g = torch.randn(interp.shape, device="cuda", generator=torch.Generator("cuda").manual_seed(4))
+    interp.backward(g)
+    c0 = r0 = 0
+    for (coords, feats), st in zip(mbs, starts):
+        b, _, n = coords.shape
+        x = dev(coords).permute(0, 2, 1)
+        f = dev(feats).permute(0, 2, 1)
+        i1, nx1 = ops.furthest_point_sample(x, S, dev(st))
+        assert torch.equal(i1, idx[c0:c0 + b]) and torch.equal(nx1, new_xyz[c0:c0 + b])
+        xyz_np = np.ascontiguousarray(coords.transpose(0, 2, 1))
+        assert np.array_equal(i1.cpu().numpy(), O.farthest_point_sample(xyz_np, S, st))
+        b1 = ops.ball_query(r, K, x, nx1)
+        assert torch.equal(b1, bq[c0:c0 + b])
+        g1 = ops.GroupPoints.apply(x, nx1, f, b1, False)
+        assert torch.equal(g1, grouped[c0:c0 + b])
+        ni, nw = ops.three_nn(x, nx1)
+        assert torch.equal(ni.reshape(-1, 3), nn_idx[r0:r0 + b * n]) and torch.equal(nw.reshape(-1, 3), nn_w[r0:r0 + b * n])
+        q = p2[c0:c0 + b].detach().clone().requires_grad_(True)
+        o1 = ops.ThreeInterpolateConcat.apply(None, q, ni, nw)
+        assert torch.equal(o1.reshape(-1, 8), interp[r0:r0 + b * n].detach())
+        o1.backward(g[r0:r0 + b * n].view(b, n, 8))
+        np.testing.assert_allclose(p2.grad[c0:c0 + b].cpu().numpy(), q.grad.cpu().numpy(), rtol=2e-5,
+                                   atol=2e-5 * float(q.grad.abs().max()))      # summation order of ~100s of fp32 terms
+        c0 += b
+        r0 += b * n
+    ops.check_status()
+
+
+def _mlp(widths, cin, two_d, seed):
+    import torch.nn as nn
+    torch.manual_seed(seed)
+    convs, bns = nn.ModuleList(), nn.ModuleList()
+    for c in widths:
+        convs.append(nn.Conv2d(cin, c, 1) if two_d else nn.Conv1d(cin, c, 1))
+        bns.append(nn.BatchNorm2d(c) if two_d else nn.BatchNorm1d(c))
+        cin = c
+    with torch.no_grad():
+        for bn in bns:
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.uniform_(-0.3, 0.3)
+    return convs.cuda(), bns.cuda()
+
+
+@pytest.mark.parametrize("rows_per_seg,cin,widths,pool_k,head", [
+    ([2560, 2048, 2560], 259, [256, 256, 512], 32, False),        # SA-like: pooled, K-aligned segments
+    ([80, 80, 64, 8], 768, [256, 256], 1, False),                  # FP4-like: segments shorter than a row tile
+    ([9590, 61120, 1031, 24000], 128, [128, 128, 128], 1, False),  # FP1-like: big ragged segments
+    ([5000, 777, 12000], 128, [128, 3], 1, True),                  # head: BN layer + narrow last conv
+    ([160, 160, 100], 7, [32, 32, 64], 20, False),                 # narrow input channels, K = 20 groups
+])
+def test_segmented_chain_equals_separate_calls(pn2, rows_per_seg, cin, widths, pool_k, head):
+    """chain_rows over concatenated mini-batches with seg_off == one chain_rows call per mini-batch: outputs, input
+    gradients, parameter gradients (summed), BatchNorm running statistics (updated segment after segment) and counters."""
+    from pn2_amd.mlp import chain_rows
+    import copy
+    convs, bns = _mlp(widths, cin, pool_k > 1, seed=5)
+    if head:
+        layers_of = lambda cv, bn: [(cv[0], bn[0], True), (cv[1], None, False)]   # noqa: E731
+    else:
+        layers_of = lambda cv, bn: [(c, b, True) for c, b in zip(cv, bn)]         # noqa: E731
+    convs2, bns2 = copy.deepcopy(convs), copy.deepcopy(bns)
+    rows = sum(rows_per_seg)
+    gen = torch.Generator("cuda").manual_seed(6)
+    x = torch.randn(rows, cin, device="cuda", generator=gen)
+    seg_off = np.concatenate([[0], np.cumsum(rows_per_seg)]).tolist()
+    xa = x.clone().requires_grad_(True)
+    ya = chain_rows(xa, layers_of(convs, bns), pool_k=pool_k, seg_off=seg_off)
+    gout = torch.randn(ya.shape, device="cuda", generator=gen)
+    ya.backward(gout)
+    outs, dxs = [], []
+    for s in range(len(rows_per_seg)):
+        xb = x[seg_off[s]:seg_off[s + 1]].clone().requires_grad_(True)
+        yb = chain_rows(xb, layers_of(convs2, bns2), pool_k=pool_k)
+        yb.backward(gout[seg_off[s] // pool_k:seg_off[s + 1] // pool_k])
+        outs.append(yb.detach())
+        dxs.append(xb.grad)
+    yb, dxb = torch.cat(outs), torch.cat(dxs)
+    scale = float(yb.abs().max())
+    assert float((ya.detach() - yb).abs().max()) <= 2e-5 * scale
+    # Gradients: the two paths merge the BatchNorm partials in different orders, so a coefficient may differ in its last
+    # bit, and a pre-activation that sits within an ulp of zero then takes the other side of the ReLU -- one row of dx
+    # moves by O(1) (measured: 1 element of 1.8 M, tools/debug_seg2.py).  Compare robustly: relative L2 and the 99.9th
+    # percentile instead of the maximum.
+    def robust_close(a, b, what):
+        d = (a - b).abs().flatten()
+        ref = float(b.abs().max())
+        assert float(d.norm()) <= 2e-3 * float(b.norm()), what
+        assert float(torch.quantile(d[: 1 << 24].float(), 0.999)) <= 1e-4 * ref + 1e-9, what
+    robust_close(xa.grad, dxb, "dx")
+    for (n1, p1), (n2, p2) in zip(list(convs.named_parameters()) + list(bns.named_parameters()),
+                                  list(convs2.named_parameters()) + list(bns2.named_parameters())):
+        if p2.grad is None:
+            assert p1.grad is None
+            continue
+        gs = float(p2.grad.abs().max())
+        if n1.endswith("bias") and isinstance(p1, torch.nn.Parameter) and p1.dim() == 1 and gs < 1e-6:
+            continue
+        # one flipped ReLU element moves single entries of a weight gradient by |dz| * |x| = O(1): L2 + a loose max
+        assert float((p1.grad - p2.grad).norm()) <= 2e-3 * float(p2.grad.norm()) + 1e-7, n1
+        assert float((p1.grad - p2.grad).abs().max()) <= 2e-2 * gs + 1e-7, n1
+    for (n1, b1), (n2, b2) in zip(bns.named_buffers(), bns2.named_buffers()):
+        if "num_batches" in n1:
+            assert int(b1) == int(b2)
+            assert int(b1) in (0, len(rows_per_seg))                           # 0: a BatchNorm the chain does not use
+        else:
+            np.testing.assert_allclose(b1.cpu().numpy(), b2.cpu().numpy(), rtol=2e-5, atol=1e-7)
+
+
+def _tree_minibatches(n_points, seed, mbs, device="cuda"):
+    from pn2_amd.synthetic import gaussian_branch_tree, rasterize
+    xyz, off, _ = gaussian_branch_tree(n_points, seed=seed)
+    rasters = [r for r in rasterize(xyz, 1.0, 1.0) if len(r) >= 3]
+    feats = np.sin(0.61 * np.arange(n_points * 4, dtype=np.float64) + 7).astype(np.float32).reshape(n_points, 4)
+    out = []
+    for k in range(0, len(rasters), mbs):
+        group = rasters[k:k + mbs]
+        nmax = max(len(r) for r in group)
+        if nmax < 32:
+            continue
+        coords = np.zeros((len(group), 3, nmax), np.float32)
+        fts = np.zeros((len(group), 4, nmax), np.float32)
+        mpad = np.zeros((len(group), nmax), bool)
+        for i, r in enumerate(group):
+            coords[i, :, :len(r)] = xyz[r].T
+            fts[i, :, :len(r)] = feats[r].T
+            mpad[i, :len(r)] = True
+        ids = np.concatenate(group)
+        moff = (np.arange(len(ids)) % 5) != 2
+        out.append({"coords": torch.from_numpy(coords).to(device), "feats": torch.from_numpy(fts).to(device),
+                    "masks_pad": torch.from_numpy(mpad).to(device), "masks_off": torch.from_numpy(moff).to(device),
+                    "point_ids": torch.from_numpy(ids).to(device)})
+    labels = {"cloud_length": n_points, "semantic_labels": torch.from_numpy((np.arange(n_points) % 3 == 0).astype(np.int64))[:, None],
+              "offset_labels": torch.from_numpy(off)}
+    return out, labels
+
+
+def _grads_close(g0, g1):
+    """Accumulated parameter gradients of the two execution modes.  They differ by fp32 summation order only, but the
+    gradients of these chains are ill-conditioned in fp32: on small rasters the reference's OWN fp32 gradient norms sit
+    up to 4e-2 from their float64-arithmetic values (tests/test_hip_parity.py, streaming fixture), and every ReLU that
+    flips on a last-bit difference of a BatchNorm coefficient moves a sum by ~1e-3 of it.  The strict, noise-calibrated
+    check of either mode is the reference's fixture; here: 3 % per parameter, 1 % over the whole gradient."""
+    gmax = max(float(g.norm()) for g in g0.values())
+    num = den = 0.0
+    for n in g0:
+        if helpers.is_pre_bn_bias(n):
+            continue
+        d, ref = float((g0[n] - g1[n]).norm()), float(g0[n].norm())
+        assert d <= 3e-2 * ref + 1e-4 * gmax, f"accumulated gradient of {n}: |diff| {d:.3e} vs |g| {ref:.3e}"
+        num += d * d
+        den += ref * ref
+    assert num ** 0.5 <= 1e-2 * den ** 0.5, f"whole gradient: {num ** 0.5:.3e} vs {den ** 0.5:.3e}"
+
+
+class _Scaler:
+    def scale(self, x):
+        return x
+
+
+@pytest.mark.parametrize("depth,host_inputs", [(5, False), (6, False), (5, True)])
+def test_fused_streaming_equals_sequential_loop(pn2, depth, host_inputs):
+    """forward_hierarchical_streaming on a 40 000-point tree (1 m rasters, mini-batches of 10): the fused whole-tree pass
+    against the sequential loop -- same seeds, hence the same FPS draws: losses, averaged predictions, accumulated
+    gradients, BatchNorm buffers.  Also with host-resident mini-batches (the reference's collate output)."""
+    from pn2_amd.PointNet2.PointNet2 import PointNet2
+    mbs, labels = _tree_minibatches(40000, seed=3, mbs=10, device="cpu" if host_inputs else "cuda")
+    assert len(mbs) >= 5
+    res = {}
+    for mode in ("sequential", "fused"):
+        os.environ["PN2_STREAMING"] = mode
+        try:
+            torch.manual_seed(11)
+            model = PointNet2(depth=depth).cuda().train()
+            torch.manual_seed(12)
+            loss, ld = model.forward_hierarchical_streaming(dict(labels, mini_batches=iter(mbs)), return_loss=True, scaler=_Scaler())
+            grads = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+            bufs = {n: b.detach().clone() for n, b in model.named_buffers()}
+            torch.manual_seed(13)
+            with torch.no_grad():
+                pred = model.forward_hierarchical_streaming(dict(labels, mini_batches=iter(mbs)), return_loss=False)
+            res[mode] = (loss, {k: float(v) for k, v in ld.items()}, grads, bufs, pred)
+        finally:
+            os.environ.pop("PN2_STREAMING", None)
+    (l0, d0, g0, b0, p0), (l1, d1, g1, b1, p1) = res["sequential"], res["fused"]
+    assert abs(l0 - l1) <= 1e-5 * abs(l0)
+    for k in d0:
+        assert abs(d0[k] - d1[k]) <= 1e-5 * abs(d0[k]) + 1e-9
+    _grads_close(g0, g1)
+    for n in b0:
+        if "num_batches" in n:
+            assert int(b0[n]) == int(b1[n])
+        else:
+            np.testing.assert_allclose(b1[n].cpu().numpy(), b0[n].cpu().numpy(), rtol=1e-4, atol=1e-5)
+    for k in p0:
+        scale = float(p0[k].abs().max())
+        assert float((p0[k] - p1[k]).abs().max()) <= 2e-4 * scale, k
+
+
+def test_fused_forward_hierarchical_equals_sequential(pn2):
+    from pn2_amd.PointNet2.PointNet2 import PointNet2
+    mbs, labels = _tree_minibatches(20000, seed=5, mbs=4)
+    res = {}
+    for mode in ("sequential", "fused"):
+        os.environ["PN2_STREAMING"] = mode
+        try:
+            torch.manual_seed(21)
+            model = PointNet2(depth=5).cuda().train()
+            torch.manual_seed(22)
+            loss, ld = model.forward_hierarchical(dict(labels, mini_batches=iter(mbs)), return_loss=True)
+            loss.backward()
+            res[mode] = (float(loss), {n: p.grad.detach().clone() for n, p in model.named_parameters()})
+        finally:
+            os.environ.pop("PN2_STREAMING", None)
+    (l0, g0), (l1, g1) = res["sequential"], res["fused"]
+    assert abs(l0 - l1) <= 1e-5 * abs(l0)
+    _grads_close(g0, g1)
