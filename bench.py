@@ -180,6 +180,7 @@ def main():
     ap.add_argument("--trees", type=int, default=1, help="monolithic: trees per GPU per step (BASELINE configs[2]: 8 x 65536)")
     ap.add_argument("--dtype", choices=["f32"], default="f32", help="arithmetic of the path (fp32 = the reference's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dump-groups", default=None, help="write every (kernel, launch shape) group of the instrumented run here")
     args = ap.parse_args()
     rasterized = args.mode == "rasterized"
     depth = args.depth if args.depth is not None else (5 if rasterized else 4)
@@ -250,6 +251,8 @@ def main():
     groups = _hip.kernel_profile(timed_steps)
     barrier()
 
+    if rank == 0 and args.dump_groups:
+        json.dump(sorted(groups, key=lambda g: -g["ms"]), open(args.dump_groups, "w"), indent=0)
     if rank == 0:
         step_ms = 1e3 * dt / args.steps
         kernels = {}

@@ -491,11 +491,37 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     }
 }
 
-__device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+// one block per channel: s1, s2 in float64 -> dgamma, dbeta and the dY coefficients (a = s1/R, b = invstd*s2/R)
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int rows, int C,
+                                                              float* __restrict__ coef, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta) {
+    __shared__ double r1[256], r2[256];
+    const int c = blockIdx.x, t = threadIdx.x;
+    double a1 = 0.0, a2 = 0.0;
+#pragma unroll 8
+    for (int k = t; k < nblk; k += 256) {
+        a1 += (double)partial[((long long)k * 2) * C + c];
+        a2 += (double)partial[((long long)k * 2 + 1) * C + c];
+    }
+    r1[t] = a1;
+    r2[t] = a2;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (t < s) {
+            r1[t] += r1[t + s];
+            r2[t] += r2[t + s];
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        const double s1 = r1[0], s2 = r2[0];
+        coef[ST_A * C + c] = (float)(s1 / (double)rows);
+        coef[ST_B * C + c] = (float)((double)coef[ST_INVSTD * C + c] * s2 / (double)rows);
+        if (dbeta) dbeta[c] += (float)s1;
+        if (dgamma) dgamma[c] += (float)s2;
+    }
 }
+
 // rows of statistics chunk k of segment s: blocks of `cpb` chunks of `crows` rows tile the segment from its first row
 __device__ __forceinline__ int chunk_rows_in_seg(const SegTable& st, int s, int k, int cpb, int crows) {
     const int row0 = st.row_off[s] + (k - st.blk_off[s] * cpb) * crows;
@@ -503,94 +529,179 @@ __device__ __forceinline__ int chunk_rows_in_seg(const SegTable& st, int s, int 
     return left < crows ? left : crows;
 }
 
-// Segmented forward finalize: one block per channel, each wavefront takes segments wave, wave + 4, ...: lanes stride over
-// the segment's (mean, M2) chunk partials (Chan's merge in float64, like bn_finalize_kernel), one coefficient block per
-// segment.  The running statistics see the segments in order -- mini-batch after mini-batch, like the reference's
-// sequential forward passes (momentum update per pass).
-__global__ __launch_bounds__(256) void bn_finalize_seg_kernel(const float* __restrict__ partial, const SegTable st, int cpb, int CH,
-                                                              int C, const float* __restrict__ gamma,
-                                                              const float* __restrict__ beta, float* __restrict__ running_mean,
-                                                              float* __restrict__ running_var, float eps, float momentum,
-                                                              float* __restrict__ coef) {
-    __shared__ double s_mean[kMaxSegs], s_var[kMaxSegs];
-    const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float gm = gamma ? gamma[c] : 1.0f, bt = beta ? beta[c] : 0.0f;
-    for (int s = wave; s < st.nseg; s += 4) {
-        const int k0 = st.blk_off[s] * cpb, k1 = st.blk_off[s + 1] * cpb;
+// ---- BatchNorm finalize, forward and backward, in two coalesced stages -----------------------------------------------
+// The GEMM epilogues (and the reduction kernels) leave per-chunk partials [chunk][2][C].  A block per CHANNEL reading
+// them walks memory with a stride of 2*C floats -- one useful float per cache line (20 us at 4096 chunks, 100+ us with
+// 13 000 chunks of a whole tree).  Instead:
+//   stage 1  grid (C/64, slices, segments): a block sums a SLICE of 64 consecutive chunks of one segment for 64 adjacent
+//            channels -- lane = channel, so every load is a full 256-byte row of the partial array -- and writes three
+//            (two) float64 sums per channel;
+//   stage 2  grid C/64: one wavefront per segment (lane = channel) adds the segment's slices in order, writes the
+//            coefficient block, then one thread per channel walks the segments in order for what is sequential by
+//            nature (running statistics: one momentum update per mini-batch; dgamma / dbeta: a fixed-order sum).
+// Forward statistics use the segment's first chunk mean as a pivot p: with d_k = m_k - p,
+//   mean = p + sum(n_k d_k) / N,   var = (sum M2_k + sum n_k d_k^2 - N (mean - p)^2) / N      (float64)
+// -- the single-pass form of Chan's merge; the pivot removes the cancellation a raw sum of squares would have.
+constexpr int SLICE = 64;   // chunks per slice
+__device__ __forceinline__ int seg_chunks(const SegTable& st, int s, int cpb) { return (st.blk_off[s + 1] - st.blk_off[s]) * cpb; }
+__device__ __forceinline__ int seg_slices(const SegTable& st, int s, int cpb) { return (seg_chunks(st, s, cpb) + SLICE - 1) / SLICE; }
+
+constexpr int FIN_W = 16;   // wavefronts per block of stage 2
+
+template <bool FWD>
+__global__ __launch_bounds__(256) void bn_slice_reduce_kernel(const float* __restrict__ partial, const SegTable st, int cpb,
+                                                              int crows, int C, double* __restrict__ sp) {
+    constexpr int NV = FWD ? 3 : 2;
+    __shared__ double red[4][NV][64];
+    const int s = blockIdx.z, j = blockIdx.y;
+    const int nchunks = seg_chunks(st, s, cpb);
+    if (j * SLICE >= nchunks) return;                        // uniform: the grid is sized for the longest segment
+    int slot = j;
+    for (int t = 0; t < s; ++t) slot += seg_slices(st, t, cpb);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const bool ok = c < C;
+    const int k0 = st.blk_off[s] * cpb;
+    const int kb = k0 + j * SLICE, ke = (j + 1) * SLICE < nchunks ? kb + SLICE : k0 + nchunks;
+    const float pivot = (FWD && ok) ? partial[((long long)k0 * 2) * C + c] : 0.0f;   // chunk k0 always holds rows
+    double a = 0.0, b = 0.0, q = 0.0;
+    for (int k = kb + w; k < ke; k += 4) {
+        const int n = chunk_rows_in_seg(st, s, k, cpb, crows);
+        if (n <= 0 || !ok) continue;
+        const float v0 = partial[((long long)k * 2) * C + c], v1 = partial[((long long)k * 2 + 1) * C + c];
+        if (FWD) {
+            const double d = (double)v0 - (double)pivot;
+            a += (double)n * d;
+            b += (double)n * d * d;
+            q += (double)v1;
+        } else {
+            a += (double)v0;
+            b += (double)v1;
+        }
+    }
+    red[w][0][lane] = a;
+    red[w][1][lane] = b;
+    if (FWD) red[w][NV - 1][lane] = q;
+    __syncthreads();
+    if (w == 0 && ok) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+            sp[((long long)slot * NV + v) * C + c] = (red[0][v][lane] + red[1][v][lane]) + (red[2][v][lane] + red[3][v][lane]);
+    }
+}
+
+__device__ __forceinline__ float ld_coherent(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Stage 2: grid (C/64, segments), one wavefront per slice of the segment (lane = channel), sums combined through LDS in
+// slice order -> the segment's coefficient block (and its (s1, s2) sums for stage 3).
+
+template <bool FWD>
+__global__ __launch_bounds__(64 * FIN_W) void bn_seg_finalize_kernel(const float* __restrict__ partial, const double* __restrict__ sp,
+                                                                     const SegTable st, int cpb, int C,
+                                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                     float eps, float* __restrict__ coef,
+                                                                     double* __restrict__ segsum) {
+    constexpr int NV = FWD ? 3 : 2;
+    __shared__ double red[FIN_W][NV][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane, s = blockIdx.y;
+    const bool ok = c < C;
+    int slot = 0;
+    for (int t = 0; t < s; ++t) slot += seg_slices(st, t, cpb);
+    const int ns = seg_slices(st, s, cpb);
+    double acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v] = 0.0;
+    for (int j = w; j < ns; j += FIN_W)
+        if (ok) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) acc[v] += sp[((long long)(slot + j) * NV + v) * C + c];
+        }
+#pragma unroll
+    for (int v = 0; v < NV; ++v) red[w][v][lane] = acc[v];
+    __syncthreads();
+    if (w == 0 && ok) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            double t = 0.0;
+            for (int k = 0; k < FIN_W; ++k) t += red[k][v][lane];
+            acc[v] = t;
+        }
         const double rows = (double)(st.row_off[s + 1] - st.row_off[s]);
-        double acc = 0.0;
-        for (int k = k0 + lane; k < k1; k += 64) {
-            const int n = chunk_rows_in_seg(st, s, k, cpb, CH);
-            if (n > 0) acc += (double)n * (double)partial[((long long)k * 2) * C + c];
-        }
-        const double mean = wave_sum_f64(acc) / rows;
-        acc = 0.0;
-        for (int k = k0 + lane; k < k1; k += 64) {
-            const int n = chunk_rows_in_seg(st, s, k, cpb, CH);
-            if (n > 0) {
-                const double d = (double)partial[((long long)k * 2) * C + c] - mean;
-                acc += (double)partial[((long long)k * 2 + 1) * C + c] + (double)n * d * d;
-            }
-        }
-        const double var = wave_sum_f64(acc) / rows;
-        if (lane == 0) {
-            float* cf = coef + (long long)s * ST_ROWS * C;
+        float* cf = coef + (long long)s * ST_ROWS * C;
+        if (FWD) {
+            const double dm = acc[0] / rows;
+            const double mean = (double)partial[((long long)st.blk_off[s] * cpb * 2) * C + c] + dm;
+            double var = (acc[2] + acc[1] - rows * dm * dm) / rows;
+            var = var > 0.0 ? var : 0.0;
             const float invstd = (float)(1.0 / sqrt(var + (double)eps));
             cf[ST_MEAN * C + c] = (float)mean;
             cf[ST_VAR * C + c] = (float)var;
             cf[ST_INVSTD * C + c] = invstd;
-            cf[ST_SCALE * C + c] = gm * invstd;
-            cf[ST_BETA * C + c] = bt;
-            s_mean[s] = mean;
-            s_var[s] = var;
+            cf[ST_SCALE * C + c] = (gamma ? gamma[c] : 1.0f) * invstd;
+            cf[ST_BETA * C + c] = beta ? beta[c] : 0.0f;
+        } else {
+            cf[ST_A * C + c] = (float)(acc[0] / rows);
+            cf[ST_B * C + c] = (float)((double)cf[ST_INVSTD * C + c] * acc[1] / rows);
+            segsum[((long long)s * 2 + 0) * C + c] = acc[0];
+            segsum[((long long)s * 2 + 1) * C + c] = acc[1];
         }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0 && running_mean) {
-        float rm = running_mean[c], rv = running_var[c];
-        for (int s = 0; s < st.nseg; ++s) {   // float after every pass, exactly like nn.BatchNorm's buffer update
-            const int rows = st.row_off[s + 1] - st.row_off[s];
-            const double unbiased = rows > 1 ? s_var[s] * (double)rows / (double)(rows - 1) : s_var[s];
-            rm = (float)((1.0 - momentum) * (double)rm + (double)momentum * s_mean[s]);
-            rv = (float)((1.0 - momentum) * (double)rv + (double)momentum * unbiased);
-        }
-        running_mean[c] = rm;
-        running_var[c] = rv;
     }
 }
 
-// Segmented backward finalize: per segment s1 = sum dzhat, s2 = sum dzhat * xhat over the segment's chunk partials ->
-// the segment's dY coefficients; dgamma / dbeta are the sums over the segments, added in segment order.
-__global__ __launch_bounds__(256) void bn_bwd_finalize_seg_kernel(const float* __restrict__ partial, const SegTable st, int cpb,
-                                                                  int crows, int C, float* __restrict__ coef,
-                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    __shared__ double s_1[kMaxSegs], s_2[kMaxSegs];
-    const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int s = wave; s < st.nseg; s += 4) {
-        const int k0 = st.blk_off[s] * cpb, k1 = st.blk_off[s + 1] * cpb;
-        double a1 = 0.0, a2 = 0.0;
-        for (int k = k0 + lane; k < k1; k += 64)
-            if (chunk_rows_in_seg(st, s, k, cpb, crows) > 0) {
-                a1 += (double)partial[((long long)k * 2) * C + c];
-                a2 += (double)partial[((long long)k * 2 + 1) * C + c];
+// Stage 3 (tiny): what is sequential over the segments.  One thread per channel walks the segments in order: one momentum
+// update of the running statistics per segment (rounded to float each time, like nn.BatchNorm's buffer updates), or the
+// fixed-order sums dgamma / dbeta.  A separate launch rather than a "last block" inside stage 2: the device-scope fences
+// that pattern needs cost ~40 us each behind a GEMM (they write back / invalidate the L2s).
+template <bool FWD>
+__global__ __launch_bounds__(64) void bn_seg_ordered_kernel(const SegTable st, int C, const float* __restrict__ coef,
+                                                            const double* __restrict__ segsum, float* __restrict__ running_mean,
+                                                            float* __restrict__ running_var, float momentum,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    constexpr int U = 8;   // segments fetched per round: the loads of a round are in flight together
+    if (FWD) {
+        float rm = running_mean[c], rv = running_var[c];
+        for (int t0 = 0; t0 < st.nseg; t0 += U) {
+            float m[U], v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = t0 + u < st.nseg ? t0 + u : st.nseg - 1;
+                const float* cf = coef + (long long)t * ST_ROWS * C;
+                m[u] = cf[ST_MEAN * C + c];
+                v[u] = cf[ST_VAR * C + c];
             }
-        a1 = wave_sum_f64(a1);
-        a2 = wave_sum_f64(a2);
-        if (lane == 0) {
-            const double rows = (double)(st.row_off[s + 1] - st.row_off[s]);
-            float* cf = coef + (long long)s * ST_ROWS * C;
-            cf[ST_A * C + c] = (float)(a1 / rows);
-            cf[ST_B * C + c] = (float)((double)cf[ST_INVSTD * C + c] * a2 / rows);
-            s_1[s] = a1;
-            s_2[s] = a2;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (t0 + u >= st.nseg) break;
+                const int rows = st.row_off[t0 + u + 1] - st.row_off[t0 + u];
+                const double var = (double)v[u];
+                const double unbiased = rows > 1 ? var * (double)rows / (double)(rows - 1) : var;
+                rm = (float)((1.0 - momentum) * (double)rm + (double)momentum * (double)m[u]);
+                rv = (float)((1.0 - momentum) * (double)rv + (double)momentum * unbiased);
+            }
         }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
+        running_mean[c] = rm;
+        running_var[c] = rv;
+    } else {
         double t1 = 0.0, t2 = 0.0;
-        for (int s = 0; s < st.nseg; ++s) {
-            t1 += s_1[s];
-            t2 += s_2[s];
+        for (int t0 = 0; t0 < st.nseg; t0 += U) {
+            double a[U], b[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int t = t0 + u < st.nseg ? t0 + u : st.nseg - 1;
+                a[u] = segsum[((long long)t * 2 + 0) * C + c];
+                b[u] = segsum[((long long)t * 2 + 1) * C + c];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (t0 + u < st.nseg) {
+                    t1 += a[u];
+                    t2 += b[u];
+                }
         }
         if (dbeta) dbeta[c] += (float)t1;
         if (dgamma) dgamma[c] += (float)t2;
@@ -771,37 +882,6 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                 }
         }
         __syncthreads();
-    }
-}
-
-// one block per channel: s1, s2 in float64 -> dgamma, dbeta and the dY coefficients (a = s1/R, b = invstd*s2/R)
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int rows, int C,
-                                                              float* __restrict__ coef, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta) {
-    __shared__ double r1[256], r2[256];
-    const int c = blockIdx.x, t = threadIdx.x;
-    double a1 = 0.0, a2 = 0.0;
-#pragma unroll 8
-    for (int k = t; k < nblk; k += 256) {
-        a1 += (double)partial[((long long)k * 2) * C + c];
-        a2 += (double)partial[((long long)k * 2 + 1) * C + c];
-    }
-    r1[t] = a1;
-    r2[t] = a2;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (t < s) {
-            r1[t] += r1[t + s];
-            r2[t] += r2[t + s];
-        }
-        __syncthreads();
-    }
-    if (t == 0) {
-        const double s1 = r1[0], s2 = r2[0];
-        coef[ST_A * C + c] = (float)(s1 / (double)rows);
-        coef[ST_B * C + c] = (float)((double)coef[ST_INVSTD * C + c] * s2 / (double)rows);
-        if (dbeta) dbeta[c] += (float)s1;
-        if (dgamma) dgamma[c] += (float)s2;
     }
 }
 
@@ -1259,33 +1339,93 @@ WgradPlan plan_wgrad(int rows, int cout, int cin, int nseg) {
     return WgradPlan{pick_tile(cout, cin, nsplit), nsplit, kps};
 }
 
-// forward finalize of one BatchNorm layer: partial chunks of `ch` rows, `cpb` of them per row block of the table
-int launch_bn_finalize(const float* partial, const Segs& S, int tile, int rows, const pn2_mlp_layer& L, hipStream_t s) {
+// Segmented finalizes keep their float64 scratch at the start of the workspace, ahead of everything else:
+// [256 B spare][per-segment (s1, s2) sums: nseg x 2 x cmax][slice sums: slices x 3 x cmax]
+struct FinScratch {
+    double* segsum;
+    double* slices;
+};
+size_t slice_region_bytes(int rows, int nseg, size_t cmax) {
+    if (nseg <= 1) return 0;                                  // one segment: the single-kernel finalizes need none
+    const size_t chunks = (size_t)pn2::ceil_div(rows, 32) + 2 * (size_t)nseg;
+    const size_t slices = (chunks + SLICE - 1) / SLICE + (size_t)nseg;
+    return align256(256 + ((size_t)nseg * 2 + slices * 3) * cmax * sizeof(double));
+}
+size_t chain_cmax(const pn2_mlp_layer* layers, int nlayers) {
+    size_t cmax = 0;
+    for (int i = 0; i < nlayers; ++i) {
+        const size_t m = layers[i].cin > layers[i].cout ? layers[i].cin : layers[i].cout;
+        cmax = cmax > m ? cmax : m;
+    }
+    return cmax;
+}
+size_t slice_region_of(int rows, const pn2_mlp_layer* layers, int nlayers, int nseg) {
+    return slice_region_bytes(rows, nseg, chain_cmax(layers, nlayers));
+}
+FinScratch fin_scratch(void* base, int nseg, size_t cmax) {
+    FinScratch f;
+    f.segsum = (double*)((char*)base + 256);
+    f.slices = f.segsum + (size_t)nseg * 2 * cmax;
+    return f;
+}
+
+// grid of stage 1: (channel groups of 64, slices of the longest segment, segments)
+dim3 slice_grid(const SegTable& st, int cpb, int C) {
+    int longest = 0;
+    for (int s = 0; s < st.nseg; ++s) {
+        const int n = (st.blk_off[s + 1] - st.blk_off[s]) * cpb;
+        longest = longest > n ? longest : n;
+    }
+    return dim3(pn2::ceil_div(C, 64), pn2::ceil_div(longest, SLICE), st.nseg);
+}
+
+// forward finalize of one BatchNorm layer: (mean, M2) partial chunks of tile/2 rows, two per row tile of the table
+int launch_bn_finalize(const float* partial, const FinScratch& fs, const Segs& S, int tile, int rows, const pn2_mlp_layer& L,
+                       hipStream_t s) {
     const int ch = tile / 2;
     if (S.nseg == 1) {
         PN2_LAUNCH("bn_finalize", 8.0 * pn2::ceil_div(rows, ch) * L.cout, 0, bn_finalize_kernel, dim3(L.cout), dim3(256), s,
                    partial, rows, ch, L.cout, L.gamma, L.beta, L.running_mean, L.running_var, L.eps, L.momentum, L.stats);
-    } else {
-        int nblk = 0;
-        const SegTable st = make_table(S, tile, &nblk);
-        PN2_LAUNCH("bn_finalize", 16.0 * nblk * L.cout, 0, bn_finalize_seg_kernel, dim3(L.cout), dim3(256), s, partial, st, 2, ch,
-                   L.cout, L.gamma, L.beta, L.running_mean, L.running_var, L.eps, L.momentum, L.stats);
+        PN2_LAUNCH_CHECK();
+        return 0;
     }
+    if (L.cout > 512) return PN2_E_BADARG;
+    int nblk = 0;
+    const SegTable st = make_table(S, tile, &nblk);
+    PN2_LAUNCH("bn_stats_reduce", 16.0 * nblk * L.cout, 0, (bn_slice_reduce_kernel<true>), slice_grid(st, 2, L.cout), dim3(256), s,
+               partial, st, 2, ch, L.cout, fs.slices);
+    PN2_LAUNCH("bn_finalize", 24.0 * (nblk * 2 / SLICE + S.nseg) * L.cout, 0, (bn_seg_finalize_kernel<true>),
+               dim3(pn2::ceil_div(L.cout, 64), S.nseg), dim3(64 * FIN_W), s, partial, (const double*)fs.slices, st, 2, L.cout,
+               L.gamma, L.beta, L.eps, L.stats, fs.segsum);
+    if (L.running_mean)
+        PN2_LAUNCH("bn_running", 8.0 * S.nseg * L.cout, 0, (bn_seg_ordered_kernel<true>), dim3(pn2::ceil_div(L.cout, 64)), dim3(64),
+                   s, st, L.cout, (const float*)L.stats, (const double*)fs.segsum, L.running_mean, L.running_var, L.momentum,
+                   (float*)nullptr, (float*)nullptr);
     PN2_LAUNCH_CHECK();
     return 0;
 }
 
-// backward finalize: `nblk` row blocks of `R` rows hold `cpb` partial chunks each
-int launch_bn_bwd_finalize(const float* partial, const Segs& S, int R, int cpb, int rows, const pn2_mlp_layer& L,
-                           hipStream_t s) {
+// backward finalize: row blocks of `R` rows hold `cpb` partial chunks each
+int launch_bn_bwd_finalize(const float* partial, const FinScratch& fs, const Segs& S, int R, int cpb, int rows,
+                           const pn2_mlp_layer& L, hipStream_t s) {
     int nblk = 0;
     const SegTable st = make_table(S, R, &nblk);
-    if (S.nseg == 1)
+    if (S.nseg == 1) {
         PN2_LAUNCH("bn_bwd_finalize", 8.0 * nblk * cpb * L.cout, 0, bn_bwd_finalize_kernel, dim3(L.cout), dim3(256), s, partial,
                    pn2::ceil_div(rows, R / cpb), rows, L.cout, L.stats, L.dgamma, L.dbeta);
-    else
-        PN2_LAUNCH("bn_bwd_finalize", 8.0 * nblk * cpb * L.cout, 0, bn_bwd_finalize_seg_kernel, dim3(L.cout), dim3(256), s,
-                   partial, st, cpb, R / cpb, L.cout, L.stats, L.dgamma, L.dbeta);
+        PN2_LAUNCH_CHECK();
+        return 0;
+    }
+    if (L.cout > 512) return PN2_E_BADARG;
+    PN2_LAUNCH("bn_stats_reduce", 8.0 * nblk * cpb * L.cout, 0, (bn_slice_reduce_kernel<false>), slice_grid(st, cpb, L.cout),
+               dim3(256), s, partial, st, cpb, R / cpb, L.cout, fs.slices);
+    PN2_LAUNCH("bn_bwd_finalize", 16.0 * (nblk * cpb / SLICE + S.nseg) * L.cout, 0, (bn_seg_finalize_kernel<false>),
+               dim3(pn2::ceil_div(L.cout, 64), S.nseg), dim3(64 * FIN_W), s, partial, (const double*)fs.slices, st, cpb, L.cout,
+               (const float*)nullptr, (const float*)nullptr, 0.0f, L.stats, fs.segsum);
+    if (L.dgamma || L.dbeta)
+        PN2_LAUNCH("bn_param_grads", 16.0 * S.nseg * L.cout, 0, (bn_seg_ordered_kernel<false>), dim3(pn2::ceil_div(L.cout, 64)),
+                   dim3(64), s, st, L.cout, (const float*)L.stats, (const double*)fs.segsum, (float*)nullptr, (float*)nullptr, 0.0f,
+                   L.dgamma, L.dbeta);
     PN2_LAUNCH_CHECK();
     return 0;
 }
@@ -1313,7 +1453,7 @@ extern "C" size_t pn2_mlp_workspace_bytes(int rows, const pn2_mlp_layer* layers,
         m = m > narrow ? m : narrow;
         need = need > m ? need : m;
     }
-    return align256(need) + 256;
+    return slice_region_of(rows, layers, nlayers, nseg) + align256(need) + 256;
 }
 
 extern "C" int pn2_mlp_chain_fwd_f32(const float* x, int64_t ldx, int rows, const pn2_mlp_layer* layers, int nlayers,
@@ -1324,6 +1464,8 @@ extern "C" int pn2_mlp_chain_fwd_f32(const float* x, int64_t ldx, int rows, cons
     const Segs S = make_segs(rows, training ? segments : nullptr);   // eval mode: one coefficient block serves every row
     if (workspace_bytes < pn2_mlp_workspace_bytes(rows, layers, nlayers, S.nseg) || !workspace) return PN2_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
+    const FinScratch sp = fin_scratch(workspace, S.nseg, chain_cmax(layers, nlayers));   // segmented finalizes' scratch
+    workspace = (char*)workspace + slice_region_of(rows, layers, nlayers, S.nseg);
     Act in{x, ldx, nullptr, 0};
     for (int i = 0; i < nlayers; ++i) {
         const pn2_mlp_layer& L = layers[i];
@@ -1353,7 +1495,7 @@ extern "C" int pn2_mlp_chain_fwd_f32(const float* x, int64_t ldx, int rows, cons
         if (st) return st;
         if (L.has_bn) {
             if (training) {
-                if ((st = launch_bn_finalize((const float*)workspace, S, tile, rows, L, s))) return st;
+                if ((st = launch_bn_finalize((const float*)workspace, sp, S, tile, rows, L, s))) return st;
             } else {
                 if (!L.running_mean || !L.running_var) return PN2_E_BADARG;
                 PN2_LAUNCH("bn_eval_coef", 36.0 * L.cout, 0, bn_eval_coef_kernel, dim3(pn2::ceil_div(L.cout, 256)), dim3(256), s,
@@ -1398,7 +1540,8 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
     const Segs S = make_segs(rows, segments);
     if (workspace_bytes < pn2_mlp_workspace_bytes(rows, layers, nlayers, S.nseg) || !workspace) return PN2_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    float* ws = (float*)workspace;
+    const FinScratch sp = fin_scratch(workspace, S.nseg, chain_cmax(layers, nlayers));
+    float* ws = (float*)((char*)workspace + slice_region_of(rows, layers, nlayers, S.nseg));
     // dz of the last layer: upstream gradient, or the max-pool scatter of it
     const float* dz = dout;
     long long lddz = layers[nlayers - 1].cout;
@@ -1437,7 +1580,7 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
                                lddz, y, (long long)L.cout, rows, L.cout, (const float*)L.stats, L.relu, ws, tb);
                 PN2_LAUNCH_CHECK();
             }
-            if ((st = launch_bn_bwd_finalize((const float*)ws, S, R, cpb, rows, L, s))) return st;
+            if ((st = launch_bn_bwd_finalize((const float*)ws, sp, S, R, cpb, rows, L, s))) return st;
         } else if (L.dbias && !(narrow_ok(L, last, pool_k) && lddz == L.cout)) {
             const int nblk = pn2::ceil_div(rows, CS_ROWS);
             PN2_LAUNCH("colsum", 4.0 * rows * L.cout, 0, colsum_kernel, dim3(nblk), dim3(256), s, dz, lddz, rows, L.cout, ws);
