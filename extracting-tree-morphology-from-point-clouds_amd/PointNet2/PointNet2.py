@@ -194,11 +194,21 @@ class PointNet2(nn.Module):
         path does not take (a padded raster shorter than the neighbourhood size or longer than 16384 points), runs
         the reference's loop mini-batch by mini-batch."""
         if os.environ.get("PN2_STREAMING", "fused") != "sequential":
-            mbs = list(batch["mini_batches"])
-            batch = dict(batch, mini_batches=mbs)
+            mbs = self._materialise(batch)
             if streaming.supported(mbs, self):
                 return streaming.run_tree(self, batch, return_loss, scaler=scaler, streaming=True)
         return self._streaming_sequential(batch, return_loss, scaler)
+
+    @staticmethod
+    def _materialise(batch):
+        """The reference's collate hands over a one-shot generator; its prediction scripts then run two models on the
+        same batch and the second sees nothing.  The stream is turned into a list IN the caller's dict, so it
+        can be walked again."""
+        mbs = batch["mini_batches"]
+        if not isinstance(mbs, list):
+            mbs = list(mbs)
+            batch["mini_batches"] = mbs
+        return mbs
 
     def _streaming_sequential(self, batch, return_loss, scaler=None):
         """The reference's loop: one forward (+ backward) per mini-batch."""
@@ -251,8 +261,7 @@ class PointNet2(nn.Module):
         """Non-streaming variant (reference lines 329-394): accumulate WITH autograd history, average, then
         compute one loss on the averaged predictions.  Fused like the streaming mode unless PN2_STREAMING=sequential."""
         if os.environ.get("PN2_STREAMING", "fused") != "sequential":
-            mbs = list(batch["mini_batches"])
-            batch = dict(batch, mini_batches=mbs)
+            mbs = self._materialise(batch)
             if streaming.supported(mbs, self):
                 return streaming.run_tree(self, batch, return_loss, streaming=False)
         sem_sum, off_sum, sem_cnt, off_cnt = self._accumulators(batch["cloud_length"], "cuda")

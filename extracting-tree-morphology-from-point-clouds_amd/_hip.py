@@ -79,6 +79,10 @@ SIGNATURES = {
     "pn2_mlp_workspace_bytes": (_sz, [_int, _lp, _int, _int]),
     "pn2_mlp_chain_fwd_f32": (_int, [_vp, _i64, _int, _lp, _int, _int, _int, _vp, _vp, _sp, _vp, _sz, _vp]),
     "pn2_mlp_chain_bwd_f32": (_int, [_vp, _i64, _int, _lp, _int, _int, _vp, _vp, _vp, _i64, _vp, _vp, _sp, _vp, _sz, _vp]),
+    "pn2_cylinder_project_f32": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _vp]),
+    "pn2_raster_ranges_f32": (_int, [_vp, _i64, _int, _vp, _int, _int, _int, _vp, _vp, _vp]),
+    "pn2_raster_keys": (_int, [_vp, _vp, _int, _int, _int, _vp, _vp]),
+    "pn2_raster_pack_f32": (_int, [_vp, _i64, _vp, _i64, _int, _vp, _vp, _int, _int, _vp, _vp, _vp, _vp]),
     "pn2_fps_ragged_workspace_bytes": (_sz, [_int, _int, _int]),
     "pn2_fps_ragged_f32": (_int, [_vp, _vp, _int, _int, _int, _vp, _vp, _vp, _vp, _sz, _vp]),
     "pn2_ball_query_ragged_f32": (_int, [_vp, _vp, _vp, _int, _int, _int, _f32, _int, _vp, _vp]),

@@ -36,8 +36,9 @@ MAX_ROWS_PER_PASS = 6_000_000       # level-0 rows (padded points) per pass: ~60
 class TreeLayout:
     """Host-side description of one pass: which mini-batches, how many rasters each, their padded lengths."""
 
-    def __init__(self, mini_batches):
+    def __init__(self, mini_batches, flat=None):
         self.mbs = mini_batches
+        self.flat = flat                  # rasters.RasterStream.flat: the pass's tensors already exist as flat buffers
         self.clouds = [int(mb["coords"].shape[0]) for mb in mini_batches]            # B_j
         self.length = [int(mb["coords"].shape[2]) for mb in mini_batches]            # N_j
         self.n_valid = [int(mb["point_ids"].shape[0]) for mb in mini_batches]
@@ -145,11 +146,16 @@ def backbone_and_heads(model, layout, device):
     point by point, i.e. the order of `masks_pad.reshape(-1)` mini-batch after mini-batch)."""
     mbs = layout.mbs
     lengths = np.repeat(layout.length, layout.clouds).tolist()
-    xyz_cf = _device_cat([mb["coords"] for mb in mbs], device, torch.float32)
     feats_cf, dim_feat = None, 0
-    if model.use_features:
-        dim_feat = int(mbs[0]["feats"].shape[1])
-        feats_cf = _device_cat([mb["feats"] for mb in mbs], device, torch.float32)
+    if layout.flat is not None:           # built on the device by rasters.build_stream: nothing to concatenate
+        xyz_cf = layout.flat["xyz_cf"]
+        if model.use_features:
+            dim_feat, feats_cf = int(mbs[0]["feats"].shape[1]), layout.flat["feats_cf"]
+    else:
+        xyz_cf = _device_cat([mb["coords"] for mb in mbs], device, torch.float32)
+        if model.use_features:
+            dim_feat = int(mbs[0]["feats"].shape[1])
+            feats_cf = _device_cat([mb["feats"] for mb in mbs], device, torch.float32)
     rc = ops.RaggedClouds(xyz_cf, feats_cf, dim_feat, lengths)
     starts = [s.pin_memory().to(device, non_blocking=True) for s in draw_starts(layout, model)]
     sas = _sa_modules(model)
@@ -174,11 +180,14 @@ def _valid_rows(layout, device):
     """Packed row index of every real point (the reference's x[masks_pad], mini-batch after mini-batch) -- the count
     is known on the host (point_ids), so no synchronisation -- plus the global point id, the offset mask and the
     mini-batch number of each."""
-    pad = _device_cat([mb["masks_pad"] for mb in layout.mbs], device)
     n_valid = int(sum(layout.n_valid))
+    if layout.flat is not None:
+        pad, ids, moff = layout.flat["masks_pad"], layout.flat["point_ids"], layout.flat["masks_off"]
+    else:
+        pad = _device_cat([mb["masks_pad"] for mb in layout.mbs], device)
+        ids = _device_cat([mb["point_ids"] for mb in layout.mbs], device, torch.long)
+        moff = _device_cat([mb["masks_off"] for mb in layout.mbs], device)
     rows = torch.nonzero_static(pad, size=n_valid).squeeze(1) if hasattr(torch, "nonzero_static") else pad.nonzero().squeeze(1)
-    ids = _device_cat([mb["point_ids"] for mb in layout.mbs], device, torch.long)
-    moff = _device_cat([mb["masks_off"] for mb in layout.mbs], device)
     counts = torch.tensor(layout.n_valid).to(device, non_blocking=True)
     seg = torch.repeat_interleave(torch.arange(layout.M, device=device), counts, output_size=n_valid)   # no sync
     return rows, ids, moff, seg
@@ -235,8 +244,10 @@ def run_tree(model, batch, return_loss, scaler=None, streaming=True):
         total = torch.zeros((), dtype=torch.float64, device=device)
         sums = torch.zeros(2, dtype=torch.float32, device=device)
     n_mb = 0
-    for chunk in _passes(batch["mini_batches"]):
-        layout = TreeLayout(chunk)
+    stream = batch["mini_batches"]
+    for chunk in _passes(stream):
+        whole = len(chunk) == len(stream)
+        layout = TreeLayout(chunk, flat=getattr(stream, "flat", None) if whole else None)
         sem_rows, off_rows = backbone_and_heads(model, layout, device)
         rows, ids, moff, seg = _valid_rows(layout, device)
         sem, off = sem_rows.index_select(0, rows), off_rows.index_select(0, rows)

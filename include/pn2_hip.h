@@ -266,6 +266,43 @@ int pn2_mlp_chain_bwd_f32(const float *x, int64_t ldx, int rows, const pn2_mlp_l
                           size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * Closest-cylinder projection       replaces Modules/Projection.py:19-114 (closest_cylinder_cuda_batch; duplicated at
+ *                                   PreProcessing/LabelGenerationCuda.py:20-110)
+ *   points [N] rows of point_stride floats (xyz first); cylinders: start [M,3], axis_unit [M,3], axis_length [M],
+ *   radius [M] (Projection.py:126-132 prepares them), ids [M] int32 or NULL (then the cylinder index is returned).
+ *   out_id [N] int32 = ID of the cylinder with the smallest distance (first minimum), out_dist [N] or NULL that
+ *   distance, out_offset [N,3] = projection point - point; with move_points_to_mantle the non-perpendicular case is
+ *   moved to the nearer end of the diameter segment (:90-105).  One launch for the whole cloud (the reference batches
+ *   1024 points against [1024, M, 3] temporaries).
+ */
+int pn2_cylinder_project_f32(const float *points, int64_t point_stride, int N, const float *start, const float *axis_unit,
+                             const float *axis_length, const float *radius, const int32_t *ids, int M,
+                             int move_points_to_mantle, int32_t *out_id, float *out_dist, float *out_offset, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Raster data path                  replaces the host loops of Modules/Pipeline/ModelPredicting.py:98-163
+ *                                   (rasterize_clouds) and Modules/DataLoading/RasterizedTreeSet.py:201-268, 390-459
+ *                                   (__getitem__ box masks, collate_fn_streaming zero padding)
+ *   bounds: per axis the ascending float32 lower and upper bounds of the boxes, laid out
+ *     [lo_x (nx) | hi_x (nx) | lo_y (ny) | hi_y (ny) | lo_z (nz) | hi_z (nz)]; a point is inside box k of an axis iff
+ *     lo[k] <= p < hi[k] (the dataset's float32 test).
+ *   pn2_raster_ranges_f32: ranges [N][6] int32 = {first_x, last_x, first_y, last_y, first_z, last_z} (empty when
+ *     last < first), count [N] = number of boxes the point falls into.
+ *   pn2_raster_keys: offset [N] = exclusive prefix sum of count; keys [sum(count)] int64 = box_id * N + point_id with
+ *     box_id = (kx * ny + ky) * nz + kz: sorting them yields the rasters in the reference's order, ascending ids inside.
+ *   pn2_raster_pack_f32: from the sorted point ids to the network input of a whole tree: cloud_table [C][4] int32 =
+ *     {padded rows before this raster, padded length N_j, first entry in sorted_ids, real length}; writes the flat
+ *     channel-first zero-padded buffers ("Ragged clouds" above) xyz_cf [3 * rows], feats_cf [F * rows] and the padding
+ *     mask [rows] (1 byte each).
+ */
+int pn2_raster_ranges_f32(const float *points, int64_t point_stride, int N, const float *bounds, int nx, int ny, int nz,
+                          int32_t *ranges, int32_t *count, void *stream);
+int pn2_raster_keys(const int32_t *ranges, const int64_t *offset, int N, int ny, int nz, int64_t *keys, void *stream);
+int pn2_raster_pack_f32(const float *points, int64_t point_stride, const float *feats, int64_t feat_stride, int F,
+                        const int64_t *sorted_ids, const int32_t *cloud_table, int C, int n_max, float *xyz_cf,
+                        float *feats_cf, uint8_t *masks_pad, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * Measurement hook (bench.py): with profiling enabled every kernel launch of the library is bracketed by two
  * HIP events on its launch stream.  pn2_prof_collect synchronises on them, aggregates by (kernel name,
  * algorithmic bytes, flops) of a launch, writes NUL-separated names and per-group totals, clears the records and

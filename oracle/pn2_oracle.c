@@ -337,4 +337,72 @@ void pn2o_cov_eig_f64(const double *pts, int N, const int64_t *nn_idx, int k_str
     }
 }
 
-int pn2o_version(void) { return 1; }
+/* =====================================================================================================================
+ * Round-2 additions.  PARITY UNPINNED: Modules/Projection.py and Modules/DataLoading/RasterizedTreeSet.py import
+ * `fastprogress`, which is not installed here, so the reference cannot be imported to generate golden vectors for them;
+ * the reference holds no fixtures or tests of its own for these functions.  What follows restates the reference's source
+ * text line by line and is checked by closed-form geometric properties in tests/test_projection.py.
+ * ===================================================================================================================== */
+
+/* torch.sum(a * b, dim=2) over 3 components and torch.norm(v, dim=2): (x + y) + z, sqrt of it */
+static float dot3p(float ax, float ay, float az, float bx, float by, float bz) { return (ax * bx + ay * by) + az * bz; }
+static float norm3(float x, float y, float z) { return sqrtf(dot3p(x, y, z, x, y, z)); }
+static float clampf_(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
+
+/* One (point, cylinder) pair of closest_cylinder_cuda_batch, Modules/Projection.py:33-105.
+ * want_point: 0 distance only; 1 also the final projection point f (mantle variant when `mantle`). */
+static float cyl_pair(const float *p, const float *s, const float *u, float len, float rad, int want_point, int mantle, float *f) {
+    const float vx = p[0] - s[0], vy = p[1] - s[1], vz = p[2] - s[2];                              /* :33 */
+    const float pl = clampf_(dot3p(vx, vy, vz, u[0], u[1], u[2]), 0.0f, len);                      /* :36-40 */
+    const float qx = s[0] + pl * u[0], qy = s[1] + pl * u[1], qz = s[2] + pl * u[2];               /* :41 */
+    const float wx = p[0] - qx, wy = p[1] - qy, wz = p[2] - qz;                                    /* :44 */
+    const float dp = dot3p(wx, wy, wz, u[0], u[1], u[2]);                                          /* :47 */
+    const int perp = fabsf(dp) <= 1e-3f;                                                           /* :48 isclose(atol=1e-3) */
+    const float rx = wx - dp * u[0], ry = wy - dp * u[1], rz = wz - dp * u[2];                     /* :51-52 */
+    float nr = norm3(rx, ry, rz);                                                                  /* :55 */
+    if (nr < 1e-8f) nr = 1e-8f;                                                                    /* :58-60 */
+    const float ax = rx / nr, ay = ry / nr, az = rz / nr;                                          /* :61 */
+    const float two_r = 2.0f * rad;
+    const float hx = 0.5f * (ax * two_r), hy = 0.5f * (ay * two_r), hz = 0.5f * (az * two_r);      /* :64-68 */
+    const float s0x = qx - hx, s0y = qy - hy, s0z = qz - hz;
+    const float t = clampf_(dot3p(p[0] - s0x, p[1] - s0y, p[2] - s0z, ax, ay, az), 0.0f, two_r);   /* :71-75 */
+    const float ox = s0x + t * ax, oy = s0y + t * ay, oz = s0z + t * az;                           /* :76 */
+    const float ux = qx + ax * rad, uy = qy + ay * rad, uz = qz + az * rad;                        /* :79 */
+    const float gx = perp ? ux : ox, gy = perp ? uy : oy, gz = perp ? uz : oz;                     /* :82 */
+    const float dist = norm3(p[0] - gx, p[1] - gy, p[2] - gz);                                     /* :85 */
+    if (want_point) {
+        if (mantle) {                                                                              /* :90-105 */
+            const float s1x = qx + hx, s1y = qy + hy, s1z = qz + hz;
+            const float d0 = norm3(ox - s0x, oy - s0y, oz - s0z), d1 = norm3(ox - s1x, oy - s1y, oz - s1z);
+            const int to_start = d0 < d1;
+            f[0] = perp ? ux : (to_start ? s0x : s1x);
+            f[1] = perp ? uy : (to_start ? s0y : s1y);
+            f[2] = perp ? uz : (to_start ? s0z : s1z);
+        } else {
+            f[0] = gx, f[1] = gy, f[2] = gz;
+        }
+    }
+    return dist;
+}
+
+/* closest_cylinder_cuda_batch (Modules/Projection.py:19-114) for all N points: ids (or cylinder index when ids == NULL),
+ * distances, offsets = projection point - point.  argmin keeps the first minimum (:88). */
+void pn2o_cylinder_project(const float *points, int N, const float *start, const float *unit, const float *length,
+                           const float *radius, const int32_t *ids, int M, int mantle, int32_t *out_id, float *out_dist,
+                           float *out_off) {
+    for (int n = 0; n < N; ++n) {
+        const float *p = points + 3 * (size_t)n;
+        float best = INFINITY, f[3];
+        int bi = 0;
+        for (int m = 0; m < M; ++m) {
+            const float d = cyl_pair(p, start + 3 * (size_t)m, unit + 3 * (size_t)m, length[m], radius[m], 0, 0, f);
+            if (d < best) { best = d; bi = m; }
+        }
+        const float d = cyl_pair(p, start + 3 * (size_t)bi, unit + 3 * (size_t)bi, length[bi], radius[bi], 1, mantle, f);
+        out_id[n] = ids ? ids[bi] : bi;
+        out_dist[n] = d;
+        for (int c = 0; c < 3; ++c) out_off[3 * (size_t)n + c] = f[c] - p[c];
+    }
+}
+
+int pn2o_version(void) { return 2; }

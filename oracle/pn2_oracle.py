@@ -207,3 +207,35 @@ def add_features(labeled_cloud):
     dist = np.linalg.norm(pts[:, :2] - pts[:, :2].mean(0), axis=1)
     return np.concatenate([labeled_cloud, normals, curvature[:, None], cnt[:, None].astype(np.float64), height[:, None],
                            vert[:, None], dist[:, None]], axis=1)
+
+
+# --------------------------------------------------------------------------------------------- round 2 (parity unpinned)
+def cylinder_axes(start, end):
+    """generate_offset_cloud_cuda_batched's preparation (Modules/Projection.py:126-132), float32: axis = end - start,
+    length = |axis|, unit = axis / max(length, 1e-8)."""
+    start = np.ascontiguousarray(start, np.float32)
+    axis = np.ascontiguousarray(end, np.float32) - start
+    length = np.sqrt((axis[:, 0] * axis[:, 0] + axis[:, 1] * axis[:, 1]) + axis[:, 2] * axis[:, 2]).astype(np.float32)
+    safe = np.where(length < np.float32(1e-8), np.float32(1e-8), length).astype(np.float32)
+    return start, (axis / safe[:, None]).astype(np.float32), length
+
+
+def cylinder_project(points, start, unit, length, radius, ids=None, mantle=True):
+    """closest_cylinder_cuda_batch (Modules/Projection.py:19-114) -> (ids int32 [N], distances f32 [N], offsets f32 [N,3])."""
+    points, pp = _f(points)
+    start, ps = _f(start)
+    unit, pu = _f(unit)
+    length, pl = _f(length)
+    radius, pr = _f(radius)
+    N, M = points.shape[0], start.shape[0]
+    out_id = np.empty(N, np.int32)
+    out_d = np.empty(N, np.float32)
+    out_o = np.empty((N, 3), np.float32)
+    i32p = ctypes.POINTER(ctypes.c_int32)
+    idp = None
+    if ids is not None:
+        ids = np.ascontiguousarray(ids, np.int32)
+        idp = ids.ctypes.data_as(i32p)
+    lib().pn2o_cylinder_project(pp, N, ps, pu, pl, pr, idp, M, int(bool(mantle)), out_id.ctypes.data_as(i32p),
+                                out_d.ctypes.data_as(_f32p), out_o.ctypes.data_as(_f32p))
+    return out_id, out_d, out_o
