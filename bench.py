@@ -53,10 +53,15 @@ def pmc_traffic(kernel):
 
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
+BF16_MFMA_PEAK_TFLOPS = 2500.0 # dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16), the ceiling of the *_bf16 contractions
 F32_MFMA_PEAK_TFLOPS = 157.3   # dense fp32-input MFMA peak (v_mfma_f32_32x32x2_f32)
 F32_VALU_PEAK_TFLOPS = 157.3   # fp32 vector peak (same 64 FLOP/clk/SIMD rate): the ceiling of the distance-scan kernels
 MFMA_KERNELS = ("gemm", "narrow")
 METRIC = "points/sec fwd+bwd, PointNet2 offset-regression, 262k-pt tree, 1/2/4/8 GPUs"
+
+
+def mfma_peak(kernel):
+    return BF16_MFMA_PEAK_TFLOPS if kernel.endswith("_bf16") else F32_MFMA_PEAK_TFLOPS
 
 
 def make_batch(n_points, seed, device, trees=1):
@@ -178,7 +183,9 @@ def main():
                                                             "5 rasterized = the shipping table)")
     ap.add_argument("--points", type=int, default=262144)
     ap.add_argument("--trees", type=int, default=1, help="monolithic: trees per GPU per step (BASELINE configs[2]: 8 x 65536)")
-    ap.add_argument("--dtype", choices=["f32"], default="f32", help="arithmetic of the path (fp32 = the reference's)")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="f32 = the reference's arithmetic (parity mode); bf16 = bfloat16 MFMA operands with fp32 accumulation in the "
+                         "large contractions (throughput mode, BASELINE configs[1]; tolerance: tests/test_bf16_mode.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dump-groups", default=None, help="write every (kernel, launch shape) group of the instrumented run here")
     args = ap.parse_args()
@@ -186,8 +193,9 @@ def main():
     depth = args.depth if args.depth is not None else (5 if rasterized else 4)
 
     load_pkg()
-    from pn2_amd import _hip, ops, parallel
+    from pn2_amd import _hip, mlp, ops, parallel
     from pn2_amd.PointNet2.PointNet2 import PointNet2
+    mlp.GEMM_PRECISION = args.dtype
 
     rank, local, world = parallel.init_from_env()
     if world != args.gpus:
@@ -277,16 +285,17 @@ def main():
             if gr["flops"] > 0:
                 mfma = name.startswith(MFMA_KERNELS)
                 row["TFLOPs"] = gr["flops"] / t / 1e12
-                row["compute_unit"] = "mfma" if mfma else "valu"
-                row["compute_frac"] = row["TFLOPs"] / (F32_MFMA_PEAK_TFLOPS if mfma else F32_VALU_PEAK_TFLOPS)
+                row["compute_unit"] = ("mfma_bf16" if name.endswith("_bf16") else "mfma") if mfma else "valu"
+                row["compute_frac"] = row["TFLOPs"] / (mfma_peak(name) if mfma else F32_VALU_PEAK_TFLOPS)
             rooflines[name] = row
         dom = max(groups, key=lambda gr: gr["ms"])            # dominant (kernel, shape) by total time
         avg_s = dom["ms"] / dom["calls"] * 1e-3
         hbm = dom["bytes"] / avg_s / 1e9
         tfl = dom["flops"] / avg_s / 1e12
-        if dom["name"].startswith(MFMA_KERNELS) and tfl / F32_MFMA_PEAK_TFLOPS > hbm / HBM_PEAK_GBS:
-            roofline = {"kernel": dom["name"], "bound": "mfma", "achieved": tfl, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": tfl / F32_MFMA_PEAK_TFLOPS, "traffic": None, "hbm_GBs": hbm, "hbm_frac": hbm / HBM_PEAK_GBS}
+        peak = mfma_peak(dom["name"])
+        if dom["name"].startswith(MFMA_KERNELS) and tfl / peak > hbm / HBM_PEAK_GBS:
+            roofline = {"kernel": dom["name"], "bound": "mfma", "achieved": tfl, "peak": peak, "unit": "TFLOP/s",
+                        "frac": tfl / peak, "traffic": None, "hbm_GBs": hbm, "hbm_frac": hbm / HBM_PEAK_GBS}
         else:
             roofline = {"kernel": dom["name"], "bound": "hbm", "achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": hbm / HBM_PEAK_GBS, "traffic": None}
@@ -303,6 +312,8 @@ def main():
         roofline.update({"algorithmic_bytes_per_launch": dom["bytes"], "algorithmic_flops_per_launch": dom["flops"],
                          "avg_launch_us": 1e6 * avg_s, "launches_per_step": dom["calls"] / args.steps,
                          "share_of_step": dom["ms"] / args.steps / step_ms})
+        mode_text = ("fp32 parity mode" if args.dtype == "f32" else
+                     "bf16-operand MFMA throughput mode (fp32 accumulation and storage; tolerance tests/test_bf16_mode.py)")
         if rasterized:
             workload = (f"PointNet2 depth {depth} fwd+loss+bwd+AdamW, the reference's streaming raster mode: one {args.points}-point "
                         f"Gaussian-branch tree per GPU as {n_rasters} one-metre rasters in {len(stream)} mini-batches of 10 "
@@ -310,12 +321,12 @@ def main():
                         f"fp32 parity mode")
         else:
             workload = (f"PointNet2 depth {depth} fwd+loss+bwd+AdamW, B={args.trees} x {args.points}-point Gaussian-branch tree(s) per "
-                        f"GPU ({'BASELINE configs[1], monolithic' if args.trees == 1 else 'BASELINE configs[2] shape'}), fp32 parity mode")
+                        f"GPU ({'BASELINE configs[1], monolithic' if args.trees == 1 else 'BASELINE configs[2] shape'}), {mode_text}")
         out = {
             "metric": METRIC,
             "value": args.points * args.trees * world * args.steps / dt, "unit": "points/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": workload, "mode": args.mode, "points_per_gpu": args.points * args.trees,
                        "trees_per_gpu": args.trees, "depth": depth,
                        "parallelism": f"dp{world} ({args.trees} tree(s) per rank, 1 flat gradient all-reduce per step)"},

@@ -29,6 +29,7 @@ namespace {
 
 constexpr int BK = 16, NT = 256;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
 enum { TR_PLAIN = 0, TR_BNRELU = 1, TR_DY = 2 };
 enum { EPI_FWD = 0, EPI_STORE = 1, EPI_SLAB = 2 };
@@ -314,7 +315,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[N
 // accumulators and LDS buffers; the quarters are summed through LDS at the end.  Deep levels have GEMMs with a few
 // hundred rows and K up to 768: a handful of workgroups whose serial K loop is pure latency -- four teams put four
 // times the loads in flight and give every SIMD four waves to interleave.
-template <bool A_T, int A_KIND, bool B_T, int B_KIND, int EPI, int TILE, bool VEC, int TEAMS>
+// BF16 (throughput mode, 128-tiles only): the operands are rounded to bfloat16 (round to nearest even) on their way from
+// the fp32 LDS image into the matrix core and multiplied by v_mfma_f32_32x32x16_bf16 -- one instruction per K-tile and
+// accumulator instead of eight fp32 ones, fp32 accumulation, everything else (staging, transforms, epilogues, what is
+// stored in HBM) unchanged.  The contraction then costs 1/8 of the matrix-pipe time and the kernel is bound by HBM.
+template <bool A_T, int A_KIND, bool B_T, int B_KIND, int EPI, int TILE, bool VEC, int TEAMS, bool BF16 = false>
 __global__ __launch_bounds__(NT * TEAMS, (TEAMS > 1 ? 1 : (EPI == EPI_STORE ? 2 : 3))) void gemm_kernel(const GemmArgs g0,
                                                                                                          const SegTable st) {
     constexpr int LD = TILE + 4, WT = TILE / 2, NI = WT / 32;
@@ -388,6 +393,27 @@ __global__ __launch_bounds__(NT * TEAMS, (TEAMS > 1 ? 1 : (EPI == EPI_STORE ? 2 
         // other LDS buffer, so the staging VALU/LDS work sits in the shadow of the (asynchronous, 64-cycle) MFMAs
         // instead of forming a separate phase during which this wave's matrix pipe idles.
         constexpr int NP = TILE * BK / (4 * NT), KQ = BK / NP;
+        if constexpr (BF16) {
+            static_assert(!BF16 || BK == 16, "one 32x32x16 MFMA consumes a whole K-tile");
+            // lane (r = lane & 31, h = lane >> 5) supplies A[row r][k = 8h + e] and B[k = 8h + e][col r], e = 0..7
+            bf16x8 af[NI], bf[NI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    af[i][e] = (__bf16)a[(8 * half + e) * LD + 32 * i];
+                    bf[i][e] = (__bf16)b[(8 * half + e) * LD + 32 * i];
+                }
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            if (kt + 1 < nk) {
+                sa.commit(g.A, As[cur ^ 1], m0, knext);
+                sb.commit(g.B, Bs[cur ^ 1], n0, knext);
+            }
+        } else
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
 #pragma unroll
@@ -1245,17 +1271,18 @@ inline int pick_tile(int M, int N, int nsplit) {
 
 // Row-tiled roles (forward, dgrad): grid.x = row tiles of the segments; wgrad: grid.z = reduction ranges of the segments
 // (`g.k_per_split` rows each), grid.x tiles the output rows (= cout).
-template <bool A_T, int A_KIND, bool B_T, int B_KIND, int EPI, int TILE, bool VEC, int TEAMS = 1>
+template <bool A_T, int A_KIND, bool B_T, int B_KIND, int EPI, int TILE, bool VEC, int TEAMS = 1, bool BF16 = false>
 int launch_gemm_tv(GemmArgs& g, const Segs& S, hipStream_t s, int* nblk_out) {
     int nblk = 0;
     const SegTable st = make_table(S, EPI == EPI_SLAB ? g.k_per_split : TILE, &nblk);
     const dim3 grid = EPI == EPI_SLAB ? dim3(pn2::ceil_div(g.M, TILE), pn2::ceil_div(g.N, TILE), nblk)
                                       : dim3(nblk, pn2::ceil_div(g.N, TILE), 1);
     if (nblk_out) *nblk_out = nblk;
-    const char* name = EPI == EPI_FWD ? "gemm_fwd" : EPI == EPI_STORE ? "gemm_dgrad" : "gemm_wgrad";
+    const char* name = BF16 ? (EPI == EPI_FWD ? "gemm_fwd_bf16" : EPI == EPI_STORE ? "gemm_dgrad_bf16" : "gemm_wgrad_bf16")
+                            : (EPI == EPI_FWD ? "gemm_fwd" : EPI == EPI_STORE ? "gemm_dgrad" : "gemm_wgrad");
     const double mk = (double)g.M * g.K * (A_KIND == TR_DY ? 2 : 1), kn = (double)g.K * g.N * (B_KIND == TR_DY ? 2 : 1);
     const double bytes = 4.0 * (mk + kn + (double)g.M * g.N * (EPI == EPI_SLAB ? nblk : 1));
-    PN2_LAUNCH(name, bytes, 2.0 * g.M * g.N * g.K, (gemm_kernel<A_T, A_KIND, B_T, B_KIND, EPI, TILE, VEC, TEAMS>), grid,
+    PN2_LAUNCH(name, bytes, 2.0 * g.M * g.N * g.K, (gemm_kernel<A_T, A_KIND, B_T, B_KIND, EPI, TILE, VEC, TEAMS, BF16>), grid,
                dim3(NT * TEAMS), s, g, st);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
@@ -1263,9 +1290,15 @@ int launch_gemm_tv(GemmArgs& g, const Segs& S, hipStream_t s, int* nblk_out) {
 
 inline long long grid_blocks(int M, int N, int tile) { return (long long)pn2::ceil_div(M, tile) * pn2::ceil_div(N, tile); }
 
+// process-wide precision of the 128-tile contractions for the calls in flight on this thread (set by the chain entry
+// points from their `precision` argument; the small-problem tiles always run fp32)
+thread_local int t_precision = PN2_PRECISION_F32;
+
 template <bool A_T, int A_KIND, bool B_T, int B_KIND, int EPI>
 int launch_gemm(GemmArgs& g, const Segs& S, int tile, hipStream_t s, int* nblk_out = nullptr) {
     const bool vec = vec_ok(g.A) && vec_ok(g.B);
+    if (tile == 128 && t_precision == PN2_PRECISION_BF16 && vec)
+        return launch_gemm_tv<A_T, A_KIND, B_T, B_KIND, EPI, 128, true, 1, true>(g, S, s, nblk_out);
     if (tile == 128)
         return vec ? launch_gemm_tv<A_T, A_KIND, B_T, B_KIND, EPI, 128, true>(g, S, s, nblk_out)
                    : launch_gemm_tv<A_T, A_KIND, B_T, B_KIND, EPI, 128, false>(g, S, s, nblk_out);
@@ -1458,8 +1491,10 @@ extern "C" size_t pn2_mlp_workspace_bytes(int rows, const pn2_mlp_layer* layers,
 
 extern "C" int pn2_mlp_chain_fwd_f32(const float* x, int64_t ldx, int rows, const pn2_mlp_layer* layers, int nlayers,
                                      int training, int pool_k, float* out, int32_t* pool_arg, const pn2_segments* segments,
-                                     void* workspace, size_t workspace_bytes, void* stream) {
+                                     int precision, void* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !layers || nlayers <= 0 || rows <= 0 || !out || (pool_k > 1 && (!pool_arg || rows % pool_k))) return PN2_E_BADARG;
+    if (precision != PN2_PRECISION_F32 && precision != PN2_PRECISION_BF16) return PN2_E_BADARG;
+    t_precision = precision;
     if (!segs_valid(rows, segments, pool_k)) return PN2_E_BADARG;
     const Segs S = make_segs(rows, training ? segments : nullptr);   // eval mode: one coefficient block serves every row
     if (workspace_bytes < pn2_mlp_workspace_bytes(rows, layers, nlayers, S.nseg) || !workspace) return PN2_E_WORKSPACE;
@@ -1533,9 +1568,11 @@ extern "C" int pn2_mlp_chain_fwd_f32(const float* x, int64_t ldx, int rows, cons
 
 extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, const pn2_mlp_layer* layers, int nlayers,
                                      int pool_k, const float* dout, const int32_t* pool_arg, float* dx, int64_t lddx,
-                                     float* scratch_a, float* scratch_b, const pn2_segments* segments, void* workspace,
-                                     size_t workspace_bytes, void* stream) {
+                                     float* scratch_a, float* scratch_b, const pn2_segments* segments, int precision,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !layers || nlayers <= 0 || rows <= 0 || !dout || !scratch_a || !scratch_b) return PN2_E_BADARG;
+    if (precision != PN2_PRECISION_F32 && precision != PN2_PRECISION_BF16) return PN2_E_BADARG;
+    t_precision = precision;
     if (!segs_valid(rows, segments, pool_k)) return PN2_E_BADARG;
     const Segs S = make_segs(rows, segments);
     if (workspace_bytes < pn2_mlp_workspace_bytes(rows, layers, nlayers, S.nseg) || !workspace) return PN2_E_WORKSPACE;

@@ -32,6 +32,13 @@ def _bn_momentum(bn, bump):
 # running sum).  Turn it off for torch.autograd.grad()-style use, which expects the gradients to be RETURNED.
 FUSED_GRAD_ACCUMULATION = True
 
+# Precision of the large contractions (include/pn2_hip.h: PN2_PRECISION_*).  "f32" is the parity mode (exact fp32 MFMA, the
+# reference's width); "bf16" rounds the MFMA operands to bfloat16 with fp32 accumulation -- a separate throughput mode with
+# its own tolerance (tests/test_bf16_mode.py, bench.py --dtype bf16).  Read when a chain is called; the backward of a chain
+# uses the precision its forward ran with.
+GEMM_PRECISION = "f32"
+_PRECISION_CODE = {"f32": 0, "bf16": 1}
+
 
 def _grad_target(leaf, value, need, dev):
     """-> (tensor the kernels accumulate into or None, gradient to return to autograd or None)."""
@@ -95,13 +102,15 @@ class _ChainFn(torch.autograd.Function):
             out = torch.empty(rows, cout_last, dtype=torch.float32, device=dev)
             arg = None
         ws = torch.empty(lib.pn2_mlp_workspace_bytes(rows, arr, n, nseg), dtype=torch.uint8, device=dev)
+        precision = _PRECISION_CODE[GEMM_PRECISION]
         flops = 2 * rows * sum(int(a.cin) * int(a.cout) for a in arr)
         nbytes = 4 * rows * (cin0 + 2 * sum(int(a.cout) for a in arr))
         _hip.call("mlp_chain_fwd", lib.pn2_mlp_chain_fwd_f32, x.data_ptr(), x.stride(0), rows, arr, n, int(training),
-                  int(pool_k), out.data_ptr(), _hip.ptr(arg), seg_ptr, ws.data_ptr(), ws.numel(), _hip.stream_ptr(),
+                  int(pool_k), out.data_ptr(), _hip.ptr(arg), seg_ptr, precision, ws.data_ptr(), ws.numel(), _hip.stream_ptr(),
                   nbytes=nbytes, flops=flops)
         ctx.meta = meta
         ctx.nseg = nseg
+        ctx.precision = precision
         ctx.arr = arr
         ctx.dims = (rows, cin0)
         ctx.save_for_backward(x, arg, *[t for t in ys if t is not None], *[t for t in stats if t is not None], *params)
@@ -161,8 +170,8 @@ class _ChainFn(torch.autograd.Function):
         flops = 4 * rows * sum(int(a.cin) * int(a.cout) for a in arr)
         nbytes = 4 * rows * (cin0 + 5 * sum(int(a.cout) for a in arr))
         _hip.call("mlp_chain_bwd", lib.pn2_mlp_chain_bwd_f32, x.data_ptr(), x.stride(0), rows, arr, n, int(meta["pool_k"]),
-                  dout.data_ptr(), _hip.ptr(arg), _hip.ptr(dx), cin0, sa.data_ptr(), sb.data_ptr(), seg_ptr, ws.data_ptr(),
-                  ws.numel(), _hip.stream_ptr(), nbytes=nbytes, flops=flops)
+                  dout.data_ptr(), _hip.ptr(arg), _hip.ptr(dx), cin0, sa.data_ptr(), sb.data_ptr(), seg_ptr, ctx.precision,
+                  ws.data_ptr(), ws.numel(), _hip.stream_ptr(), nbytes=nbytes, flops=flops)
         return (dx, None, *grads)
 
 

@@ -256,14 +256,23 @@ typedef struct pn2_segments {
     const int32_t *row_off;
 } pn2_segments;
 
+/* precision of the large (128-row-tile) contractions of a chain call:
+ *   PN2_PRECISION_F32   v_mfma_f32_32x32x2_f32: exact fp32 products and sums -- the parity mode, the reference's width
+ *                       (PointNet2.py:146 disables autocast around the backbone);
+ *   PN2_PRECISION_BF16  operands rounded to bfloat16 (nearest even) in front of v_mfma_f32_32x32x16_bf16, fp32
+ *                       accumulation; activations, statistics and gradients stay fp32 in memory.  Throughput mode with
+ *                       its own, looser tolerance (tests/test_bf16_mode.py); small layers still run fp32. */
+#define PN2_PRECISION_F32 0
+#define PN2_PRECISION_BF16 1
+
 size_t pn2_mlp_workspace_bytes(int rows, const pn2_mlp_layer *layers, int nlayers, int nseg);
 int pn2_mlp_chain_fwd_f32(const float *x, int64_t ldx, int rows, const pn2_mlp_layer *layers, int nlayers,
                           int training, int pool_k, float *out, int32_t *pool_arg, const pn2_segments *segments,
-                          void *workspace, size_t workspace_bytes, void *stream);
+                          int precision, void *workspace, size_t workspace_bytes, void *stream);
 int pn2_mlp_chain_bwd_f32(const float *x, int64_t ldx, int rows, const pn2_mlp_layer *layers, int nlayers,
                           int pool_k, const float *dout, const int32_t *pool_arg, float *dx, int64_t lddx,
-                          float *scratch_a, float *scratch_b, const pn2_segments *segments, void *workspace,
-                          size_t workspace_bytes, void *stream);
+                          float *scratch_a, float *scratch_b, const pn2_segments *segments, int precision,
+                          void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Closest-cylinder projection       replaces Modules/Projection.py:19-114 (closest_cylinder_cuda_batch; duplicated at

@@ -1,0 +1,90 @@
+"""GPU: the bf16-operand MFMA throughput mode (mlp.GEMM_PRECISION = "bf16"; BASELINE configs[1] names bf16) -- a separate
+mode with its own tolerance; the parity mode stays fp32.
+
+What is rounded: the two operands of every large (128-row-tile) contraction, to bfloat16 (8 significant bits), in front of
+v_mfma_f32_32x32x16_bf16; accumulation, statistics, activations in memory and all small layers stay fp32.  Expected error
+per contraction ~ 2^-9 * sqrt(K) relative to the operand magnitudes; stated bars (measured values are printed):
+  * one 128 -> 128 -> 128 chain against the fp32 mode: forward 1.5e-2 of the largest magnitude; gradients 3e-2 in relative
+    L2 norm (a bf16-sized change of a pre-activation flips the ReLU of every element that sits within ~0.5 % of zero, and
+    each flip moves single gradient entries by O(1): the maximum error says nothing, the L2 error does);
+  * whole PointNet2(depth 5) forward on a 16 384-point tree against the float64-layer-arithmetic yardstick of the torch-CPU
+    restatement (the same one the fp32 mode meets at 1e-4): 3e-2 of the largest offset.
+"""
+import contextlib
+
+import numpy as np
+import pytest
+import torch
+
+import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+@contextlib.contextmanager
+def precision(mode):
+    from pn2_amd import mlp
+    old = mlp.GEMM_PRECISION
+    mlp.GEMM_PRECISION = mode
+    try:
+        yield
+    finally:
+        mlp.GEMM_PRECISION = old
+
+
+def test_bf16_chain_close_to_fp32_chain():
+    helpers.load_pkg()
+    from pn2_amd.mlp import chain_rows
+    from test_streaming import _mlp
+    rows, cin = 65536, 128
+    convs, bns = _mlp([128, 128, 128], cin, False, seed=3)
+    layers = [(c, b, True) for c, b in zip(convs, bns)]
+    x = torch.randn(rows, cin, device="cuda", generator=torch.Generator("cuda").manual_seed(1))
+    gout = torch.randn(rows, 128, device="cuda", generator=torch.Generator("cuda").manual_seed(2))
+    res = {}
+    for mode in ("f32", "bf16"):
+        for p in list(convs.parameters()) + list(bns.parameters()):
+            p.grad = None
+        with precision(mode):
+            xa = x.clone().requires_grad_(True)
+            y = chain_rows(xa, layers)
+            y.backward(gout)
+        res[mode] = (y.detach(), xa.grad, [p.grad.clone() for p in convs.parameters() if p.grad is not None])
+    (y0, d0, w0), (y1, d1, w1) = res["f32"], res["bf16"]
+    ey = float((y0 - y1).abs().max() / y0.abs().max())
+    ed = float((d0 - d1).norm() / d0.norm())
+    ew = max(float((a - b).norm() / a.norm()) for a, b in zip(w0, w1) if float(a.abs().max()) > 1e-6)
+    print(f"bf16 vs fp32 chain: out {ey:.2e} of the largest magnitude; relative L2: dx {ed:.2e}, dW {ew:.2e}")
+    assert 1e-5 < ey <= 1.5e-2 and ed <= 3e-2 and ew <= 3e-2            # > 1e-5: the mode really ran
+
+
+def test_bf16_model_forward_against_f64_yardstick():
+    helpers.load_pkg()
+    from oracle import torch_port as P
+    from pn2_amd.PointNet2.PointNet2 import PointNet2
+    from test_round2 import _f64_layers, _tree_batch
+    _, batch = _tree_batch(16384, seed=0)
+    torch.manual_seed(77)
+    ref = P.PortPointNet2(depth=5).train()
+    torch.manual_seed(77)
+    model = PointNet2(depth=5).train().cuda()
+    P.STABLE_SORT = True
+    try:
+        with _f64_layers(), torch.no_grad():
+            torch.manual_seed(5)
+            _, off64 = ref(batch["coords"], batch["feats"])
+    finally:
+        P.STABLE_SORT = False
+    gb = {k: v.cuda() for k, v in batch.items()}
+    out = {}
+    for mode in ("f32", "bf16"):
+        state = {k: v.clone() for k, v in model.state_dict().items()}
+        with precision(mode), torch.no_grad():
+            torch.manual_seed(5)
+            out[mode] = model(gb, return_loss=False)["offset_predictions"].cpu().numpy()
+        model.load_state_dict(state)
+    scale = float(np.abs(off64.numpy()).max())
+    e32 = float(np.abs(out["f32"] - off64.numpy()).max()) / scale
+    e16 = float(np.abs(out["bf16"] - off64.numpy()).max()) / scale
+    print(f"depth-5 offsets vs the float64 yardstick: fp32 mode {e32:.2e}, bf16 mode {e16:.2e} (of the largest offset)")
+    assert e32 <= 1e-4 and 1e-5 < e16 <= 3e-2
