@@ -79,11 +79,14 @@ class MLP(nn.Sequential):
         nn.init.constant_(self[-1].bias, 0)
 
 
-def _group_mlp_max(grouped, convs, bns, seg_off=None):
+def _group_mlp_max(grouped, convs, bns, seg_off=None, coords_first=0):
     """grouped [B,S,K,C] -> per-group MLP and max over K -> [B,S,C_out] (reference blocks.py:93-98).
-    seg_off: row offsets of the mini-batches the B clouds belong to (whole-tree execution, streaming.py)."""
+    seg_off: row offsets of the mini-batches the B clouds belong to (whole-tree execution, streaming.py).
+    coords_first: number of leading channels that are centred coordinates (no gradient flows into them: the input
+    gradient of the chain is then computed for the feature channels only)."""
     B, S, K, C = grouped.shape
-    y = chain_rows(grouped.reshape(B * S * K, C), [(c, b, True) for c, b in zip(convs, bns)], pool_k=K, seg_off=seg_off)
+    y = chain_rows(grouped.reshape(B * S * K, C), [(c, b, True) for c, b in zip(convs, bns)], pool_k=K, seg_off=seg_off,
+                   dx_first_col=coords_first)
     return y.view(B, S, -1)
 
 
@@ -106,7 +109,8 @@ class PointNetSetAbstraction(nn.Module):
             new_xyz, grouped = sample_and_group_all(xyz_t, pts_t)
         else:
             new_xyz, grouped, _, _ = _sample_and_group_i32(self.npoint, self.radius, self.nsample, xyz_t, pts_t)
-        pooled = _group_mlp_max(grouped, self.mlp_convs, self.mlp_bns)
+        # [xyz - centroid, feats]: the 3 leading channels need no gradient (GroupPoints differentiates the features only)
+        pooled = _group_mlp_max(grouped, self.mlp_convs, self.mlp_bns, coords_first=0 if self.group_all or pts_t is None else 3)
         return new_xyz.permute(0, 2, 1), pooled.permute(0, 2, 1)
 
 

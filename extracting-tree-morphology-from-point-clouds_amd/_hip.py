@@ -78,7 +78,7 @@ SIGNATURES = {
                                 ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _int]),
     "pn2_mlp_workspace_bytes": (_sz, [_int, _lp, _int, _int]),
     "pn2_mlp_chain_fwd_f32": (_int, [_vp, _i64, _int, _lp, _int, _int, _int, _vp, _vp, _sp, _int, _vp, _sz, _vp]),
-    "pn2_mlp_chain_bwd_f32": (_int, [_vp, _i64, _int, _lp, _int, _int, _vp, _vp, _vp, _i64, _vp, _vp, _sp, _int, _vp, _sz, _vp]),
+    "pn2_mlp_chain_bwd_f32": (_int, [_vp, _i64, _int, _lp, _int, _int, _vp, _vp, _vp, _i64, _int, _vp, _vp, _sp, _int, _vp, _sz, _vp]),
     "pn2_cylinder_project_f32": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _vp]),
     "pn2_raster_ranges_f32": (_int, [_vp, _i64, _int, _vp, _int, _int, _int, _vp, _vp, _vp]),
     "pn2_raster_keys": (_int, [_vp, _vp, _int, _int, _int, _vp, _vp]),

@@ -1568,9 +1568,10 @@ extern "C" int pn2_mlp_chain_fwd_f32(const float* x, int64_t ldx, int rows, cons
 
 extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, const pn2_mlp_layer* layers, int nlayers,
                                      int pool_k, const float* dout, const int32_t* pool_arg, float* dx, int64_t lddx,
-                                     float* scratch_a, float* scratch_b, const pn2_segments* segments, int precision,
-                                     void* workspace, size_t workspace_bytes, void* stream) {
+                                     int dx_first_col, float* scratch_a, float* scratch_b, const pn2_segments* segments,
+                                     int precision, void* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !layers || nlayers <= 0 || rows <= 0 || !dout || !scratch_a || !scratch_b) return PN2_E_BADARG;
+    if (dx_first_col < 0 || dx_first_col >= layers[0].cin) return PN2_E_BADARG;
     if (precision != PN2_PRECISION_F32 && precision != PN2_PRECISION_BF16) return PN2_E_BADARG;
     t_precision = precision;
     if (!segs_valid(rows, segments, pool_k)) return PN2_E_BADARG;
@@ -1692,17 +1693,20 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
         //      taken from the accumulators in the epilogue (no separate pass over dX and Y)
         const bool need_dx = i > 0 || dx != nullptr;
         if (need_dx) {
-            float* target = i > 0 ? bufs[which] : dx;
+            // the chain's input gradient may be wanted from column dx_first_col on only (the centred coordinates in
+            // front of a grouped set-abstraction input carry no gradient): fewer -- and better filled -- column tiles
+            const int skip = i == 0 ? dx_first_col : 0;
+            float* target = i > 0 ? bufs[which] : dx + skip;
             const long long ldt = i > 0 ? L.cin : lddx;
             GemmArgs g{};
             g.A = dy;                       // [rows = M][cout = K]
-            g.B = plain(L.weight, L.cin, L.cout, L.cin);   // [cout = K][cin = N], direct layout
+            g.B = plain(L.weight + skip, L.cin, L.cout, L.cin - skip);   // [cout = K][cin = N], direct layout
             g.M = rows;
-            g.N = L.cin;
+            g.N = L.cin - skip;
             g.K = L.cout;
             g.C = target;
             g.ldc = ldt;
-            const int tile = pick_tile(rows, L.cin, 1);
+            const int tile = pick_tile(rows, L.cin - skip, 1);
             if (i > 0 && layers[i - 1].has_bn) {
                 g.partial = ws;
                 g.ey = layers[i - 1].y;

@@ -162,7 +162,11 @@ class _ChainFn(torch.autograd.Function):
                 maxc = max(maxc, cin)
             cin = spec["cout"]
         maxc = max(maxc, cin)
+        skip = int(meta.get("dx_first_col", 0))
+        # columns in front of `skip` are never computed: zero them so that the tensor handed to autograd is defined
         dx = torch.empty(rows, cin0, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        if dx is not None and skip:
+            dx[:, :skip].zero_()
         sa = torch.empty(rows * maxc, dtype=torch.float32, device=dev)
         sb = torch.empty(rows * maxc, dtype=torch.float32, device=dev)
         seg_ptr, seg_keep = _hip.segments_arg(meta.get("seg_off") if ctx.nseg > 1 else None)
@@ -170,17 +174,18 @@ class _ChainFn(torch.autograd.Function):
         flops = 4 * rows * sum(int(a.cin) * int(a.cout) for a in arr)
         nbytes = 4 * rows * (cin0 + 5 * sum(int(a.cout) for a in arr))
         _hip.call("mlp_chain_bwd", lib.pn2_mlp_chain_bwd_f32, x.data_ptr(), x.stride(0), rows, arr, n, int(meta["pool_k"]),
-                  dout.data_ptr(), _hip.ptr(arg), _hip.ptr(dx), cin0, sa.data_ptr(), sb.data_ptr(), seg_ptr, ctx.precision,
+                  dout.data_ptr(), _hip.ptr(arg), _hip.ptr(dx), cin0, skip, sa.data_ptr(), sb.data_ptr(), seg_ptr, ctx.precision,
                   ws.data_ptr(), ws.numel(), _hip.stream_ptr(), nbytes=nbytes, flops=flops)
         return (dx, None, *grads)
 
 
-def chain_rows(x, layers, pool_k=1, seg_off=None):
+def chain_rows(x, layers, pool_k=1, seg_off=None, dx_first_col=0):
     """x [R, C_in] fp32 rows; layers: iterable of (conv, bn_or_None, relu: bool).
     -> [R, C_out], or [R // pool_k, C_out] (max over each group of pool_k consecutive rows) when pool_k > 1.
     seg_off: optional ascending row offsets [0, ..., R] of the mini-batches the rows are made of (whole-tree execution):
     train-mode BatchNorm then works per segment, exactly as if the segments had been separate calls, and every layer's
-    running statistics / num_batches_tracked advance once per segment."""
+    running statistics / num_batches_tracked advance once per segment.
+    dx_first_col: the gradient w.r.t. x is only needed from this column on (the leading columns come back as zeros)."""
     layers = list(layers)
     if not layers:
         return x
@@ -203,7 +208,7 @@ def chain_rows(x, layers, pool_k=1, seg_off=None):
             spec["leaves"] = (conv.weight, conv.bias, None, None)
         specs.append(spec)
     # a chain is either all batch statistics or all running statistics (module.train()/eval() sets them together)
-    meta = {"layers": specs, "pool_k": int(pool_k), "training": training}
+    meta = {"layers": specs, "pool_k": int(pool_k), "training": training, "dx_first_col": int(dx_first_col)}
     nseg = 1
     if seg_off is not None and len(seg_off) > 2 and training:
         if any(bn is not None and bn.momentum is None for _, bn, _ in layers):

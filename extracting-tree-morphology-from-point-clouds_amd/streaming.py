@@ -114,7 +114,8 @@ def _sa_level(sa, xyz_t, pts_t, start, layout, rc=None):
             idx = ops.ball_query(radius, K, xyz_t, new_xyz)
             grouped = ops.GroupPoints.apply(xyz_t, new_xyz, pts_t, idx, msg)
         rows_per_cloud = grouped.shape[1] * grouped.shape[2]
-        outs.append(_group_mlp_max(grouped, convs, bns, seg_off=layout.seg_rows(rows_per_cloud)))
+        outs.append(_group_mlp_max(grouped, convs, bns, seg_off=layout.seg_rows(rows_per_cloud),
+                                   coords_first=0 if (msg or rc is not None or pts_t is None) else 3))
     return new_xyz, (outs[0] if len(outs) == 1 else torch.cat(outs, dim=-1))
 
 

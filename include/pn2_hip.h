@@ -226,7 +226,8 @@ int pn2_three_interpolate_grad_ragged_f32(const float *dout, int64_t out_stride,
  *
  * Backward: dout has the shape of out; gradients are ACCUMULATED (+=) into dweight/dbias/dgamma/dbeta where
  * non-NULL (dbias of a conv feeding a BatchNorm is analytically zero and is left untouched); dx [rows][cin_0]
- * (row stride lddx) is written when non-NULL.  scratch_a/b: two buffers of rows * max(cin_i, cout_last) floats.
+ * (row stride lddx) is written when non-NULL, from column dx_first_col on (columns in front of it are left untouched:
+ * the 3 centred coordinates that lead a grouped set-abstraction input carry no gradient).  scratch_a/b: two buffers of rows * max(cin_i, cout_last) floats.
  * workspace: pn2_mlp_workspace_bytes(rows, layers, nlayers, nseg) bytes for either direction.
  */
 typedef struct pn2_mlp_layer {
@@ -271,8 +272,8 @@ int pn2_mlp_chain_fwd_f32(const float *x, int64_t ldx, int rows, const pn2_mlp_l
                           int precision, void *workspace, size_t workspace_bytes, void *stream);
 int pn2_mlp_chain_bwd_f32(const float *x, int64_t ldx, int rows, const pn2_mlp_layer *layers, int nlayers,
                           int pool_k, const float *dout, const int32_t *pool_arg, float *dx, int64_t lddx,
-                          float *scratch_a, float *scratch_b, const pn2_segments *segments, int precision,
-                          void *workspace, size_t workspace_bytes, void *stream);
+                          int dx_first_col, float *scratch_a, float *scratch_b, const pn2_segments *segments,
+                          int precision, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Closest-cylinder projection       replaces Modules/Projection.py:19-114 (closest_cylinder_cuda_batch; duplicated at
