@@ -25,43 +25,9 @@ namespace {
 
 using u64 = unsigned long long;
 using f2 = __attribute__((ext_vector_type(2))) float;
-using lds_f32 = __attribute__((address_space(3))) float;
 constexpr u64 kValid = 1ull << 63;
 constexpr int kMaxG = 64;
-constexpr unsigned kSpinLimitDefault = 1u << 22;   // polls before a hand-off is declared dead (PN2_FPS_SPIN_LIMIT overrides)
-// status bits OR-ed into the caller's status word when a launch dies (include/pn2_hip.h: PN2_STATUS_*)
-constexpr int kStatusHandoff = PN2_STATUS_FPS_HANDOFF, kStatusArrival = PN2_STATUS_FPS_ARRIVAL;
-
-// Launch-wide knobs passed by value to every multi-workgroup kernel.
-struct Knobs {
-    unsigned spin_limit;   // bounded spins: a member that never shows up kills the launch instead of hanging it
-    int force_fallback;    // PN2_FPS_FORCE_FALLBACK: take the placement-independent grouping even when XCD-local groups exist
-    int* status;           // caller's sticky status word (device), may be null
-};
-
-// Rows a dead launch never produces must not look like samples.  The XCD kernels fill ALL output rows with -1 (indices) /
-// NaN (centroids) before their grid-wide arrival count -- workgroup i takes clouds i, i + grid, ... --, so the fill is
-// complete and released before any workgroup learns its role and writes a sample; a launch that dies in the arrival phase
-// leaves the fill behind.  (In the kernel rather than as two memset nodes ahead of it: those cost ~30 us per call.)
-__device__ __forceinline__ void poison_rows(int32_t* out_idx, float* out_xyz, size_t first, int count, int tid, int nthreads) {
-    for (int e = tid; e < count; e += nthreads) out_idx[first + e] = -1;
-    if (out_xyz)
-        for (int e = tid; e < 3 * count; e += nthreads) out_xyz[3 * first + e] = __uint_as_float(0xFFFFFFFFu);
-}
-
-// One poll of a bounded spin.  Returns false when the launch is dead: this waiter ran out of polls (it raises the
-// launch's error word, which every other waiter of the launch polls) or somebody else already did.  A dead launch is
-// never waited on again: every workgroup leaves at its next barrier, the rows it did not produce keep the -1 / NaN
-// fill written ahead of the kernel, and the caller's status word says why (ops.check_status raises on it).
-__device__ __forceinline__ bool spin_alive(unsigned& spins, const Knobs& kn, unsigned* err, int why) {
-    if (++spins > kn.spin_limit) {
-        atomicOr(err, 1u);
-        if (kn.status) atomicOr(kn.status, why);
-        return false;
-    }
-    if ((spins & 127u) == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
-    return true;
-}
+constexpr unsigned kSpinLimit = 1u << 22;
 #ifdef PN2_FPS_DIAG
 constexpr size_t kHdr = 256;
 #else
@@ -79,24 +45,18 @@ __device__ __forceinline__ void st_granule(u64* p, u64 v) {
 // round trip of the (fire-and-forget) result stores of the step, which costs more than the step itself.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// GROUPED = false: one workgroup per cloud (G == 1) -- the exchange code is not even compiled in, the loop stays tight.
-// RAGGED: per-cloud offsets (whole-tree batches, G == 1 only); compiled separately so that the regular kernels keep
-// wave-uniform (scalar) cloud sizes and strides.
-template <int PPT, int T, bool GROUPED, bool RAGGED = false>
+template <int PPT, int T>
 __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, int64_t sb, int64_t sn, int64_t sc,
                                                 int B, int N, int npoint, const int64_t* __restrict__ start,
                                                 int32_t* __restrict__ out_idx, float* __restrict__ out_xyz,
-                                                u64* gran, unsigned* err, int G, int groups, Knobs kn, const int* coff) {
+                                                u64* gran, unsigned* err, int G, int groups) {
     constexpr int NW = T / 64;
     __shared__ u64 s_key[2][NW];
     __shared__ float s_xyz[2][NW][3];
     __shared__ u64 s_win[2];
     __shared__ float s_wxyz[2][3];
-    __shared__ int s_dead;
 
     const int tid = threadIdx.x;
-    if (tid == 0) s_dead = 0;
-    __syncthreads();
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int g = blockIdx.x % G;
@@ -104,27 +64,25 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
     const int base = g * (T * PPT) + tid;
 
     for (int b = grp; b < B; b += groups) {
-        const pn2::CloudView cv = RAGGED ? pn2::cloud_view(xyz, sb, sn, sc, N, coff, b, 3)
-                                         : pn2::CloudView{xyz + (int64_t)b * sb, sn, sc, N};
-        const float* p = cv.p;
+        const float* p = xyz + (int64_t)b * sb;
         float x[PPT], y[PPT], z[PPT], d[PPT];
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
             const int n = base + j * T;
-            const bool ok = n < cv.n;
-            const float* q = p + (int64_t)(ok ? n : 0) * cv.sn;
+            const bool ok = n < N;
+            const float* q = p + (int64_t)(ok ? n : 0) * sn;
             x[j] = q[0];
-            y[j] = q[cv.sc];
-            z[j] = q[2 * cv.sc];
+            y[j] = q[sc];
+            z[j] = q[2 * sc];
             d[j] = ok ? 1e10f : -1.0f;  // -1 marks a slot beyond N: never a maximum, never updated
         }
         int far = (int)start[b];
         float cx, cy, cz;
         {
-            const float* c = p + (int64_t)far * cv.sn;
+            const float* c = p + (int64_t)far * sn;
             cx = c[0];
-            cy = c[cv.sc];
-            cz = c[2 * cv.sc];
+            cy = c[sc];
+            cz = c[2 * sc];
         }
         u64* gb = gran + (size_t)b * npoint * 4 * G;
 
@@ -190,7 +148,7 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
             // chain in every thread).  With G > 1 only the publishing wave needs it.
             u64 k = 0;
             float nx = 0.f, ny = 0.f, nz = 0.f;
-            if (!GROUPED || wave == 0) {
+            if (G == 1 || wave == 0) {
                 int kw = 0;
                 if (NW <= 4) {
                     k = s_key[buf][0];
@@ -207,14 +165,11 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
                     k = pn2::wave_max_key((unsigned)(cand >> 32), (unsigned)cand);
                     kw = (int)__builtin_ctzll(__ballot(lane < NW && cand == k));
                 }
-                // explicit LDS address space: with a run-time wave index the compiler otherwise falls back to FLAT loads here
-                // (src_shared_base + vmcnt wait: +130 ns per sample, measured against the round-1 build)
-                const lds_f32* cand_xyz = (const lds_f32*)&s_xyz[buf][0][0];
-                nx = cand_xyz[kw * 3];
-                ny = cand_xyz[kw * 3 + 1];
-                nz = cand_xyz[kw * 3 + 2];
+                nx = s_xyz[buf][kw][0];
+                ny = s_xyz[buf][kw][1];
+                nz = s_xyz[buf][kw][2];
             }
-            if (GROUPED) {
+            if (G > 1) {
                 if (wave == 0) {
                     u64* slot = gb + (size_t)i * 4 * G;
                     const unsigned tag = (unsigned)(i + 1);
@@ -236,8 +191,8 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
                             const bool ok = ((v0 & kValid) != 0) & ((unsigned)(v1 >> 32) == tag) &
                                             ((unsigned)(v2 >> 32) == tag) & ((unsigned)(v3 >> 32) == tag);
                             if (ok) break;
-                            if (!spin_alive(spins, kn, err, kStatusHandoff)) {  // a member never arrived: the launch is dead
-                                s_dead = 1;
+                            if (++spins > kSpinLimit) {  // a member never arrived: flag it and let the grid drain
+                                atomicOr(err, 1u);
                                 v0 = kValid;
                                 break;
                             }
@@ -258,7 +213,6 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
                 STAMP(4);  // group reduce + LDS write
                 lds_barrier();
                 STAMP(5);  // barrier 2
-                if (s_dead) return;   // uniform: every thread reads the flag after the same barrier
                 k = s_win[buf];
                 nx = s_wxyz[buf][0];
                 ny = s_wxyz[buf][1];
@@ -307,7 +261,7 @@ __device__ __forceinline__ unsigned xcc_id() {
 
 // Phase 0 of the XCD-local kernels, run by one lane: which XCD did this workgroup land on, which group of G same-XCD
 // workgroups (or, failing that, of consecutive block ids) does it belong to.  s_role = {group or -1, rank, #groups, local}.
-__device__ void xcd_roles(XcdHeader* hdr, int G, int* s_role, const Knobs& kn) {
+__device__ void xcd_roles(XcdHeader* hdr, int G, int* s_role) {
         const unsigned x = xcc_id();
         const unsigned rank = atomicAdd(&hdr->cnt[x], 1u);
         __threadfence();
@@ -315,7 +269,8 @@ __device__ void xcd_roles(XcdHeader* hdr, int G, int* s_role, const Knobs& kn) {
         unsigned spins = 0;
         bool ok = true;
         while (__hip_atomic_load(&hdr->arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
-            if (!spin_alive(spins, kn, &hdr->err, kStatusArrival)) {  // the grid is not co-resident (busy GPU)
+            if (++spins > kSpinLimit) {
+                atomicOr(&hdr->err, 2u);
                 ok = false;
                 break;
             }
@@ -329,7 +284,7 @@ __device__ void xcd_roles(XcdHeader* hdr, int G, int* s_role, const Knobs& kn) {
             total += c;
         }
         int group = -1, grank = 0, ngroups = 0, local = 0;
-        if (ok && total > 0 && !kn.force_fallback) {  // XCD-local groups
+        if (ok && total > 0) {  // XCD-local groups
             local = 1;
             ngroups = total;
             if ((int)rank < mine * G) {
@@ -353,9 +308,8 @@ template <bool PERWAVE>
 __global__ __launch_bounds__(kXT) void fps_xcd_kernel(const float* __restrict__ xyz, int64_t sb, int64_t sn, int64_t sc,
                                                       int B, int N, int npoint, const int64_t* __restrict__ start,
                                                       int32_t* __restrict__ out_idx, float* __restrict__ out_xyz,
-                                                      u64* gran, XcdHeader* hdr, int G, Knobs kn) {
+                                                      u64* gran, XcdHeader* hdr, int G) {
     constexpr int T = kXT, NW = T / 64;
-    __shared__ int s_dead;
     __shared__ u64 s_key[2][NW];
     __shared__ float s_xyz[2][NW][3];
     __shared__ u64 s_win[2];
@@ -367,13 +321,8 @@ __global__ __launch_bounds__(kXT) void fps_xcd_kernel(const float* __restrict__ 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-    // ---- phase 0: fill the outputs, then: where did this workgroup land?  (one lane; everything below is wave-uniform)
-    for (int b = blockIdx.x; b < B; b += gridDim.x) poison_rows(out_idx, out_xyz, (size_t)b * npoint, npoint, tid, T);
-    __syncthreads();   // every store of the fill has left before thread 0's release + arrival in xcd_roles
-    if (tid == 0) {
-        s_dead = 0;
-        xcd_roles(hdr, G, s_role, kn);
-    }
+    // ---- phase 0: where did this workgroup land?  (one lane; everything below is wave-uniform)
+    if (tid == 0) xcd_roles(hdr, G, s_role);
     __syncthreads();
     const int group = s_role[0], g = s_role[1], ngroups = s_role[2];
     const bool local = s_role[3] != 0;
@@ -509,8 +458,8 @@ __global__ __launch_bounds__(kXT) void fps_xcd_kernel(const float* __restrict__ 
                         }
                     }
                     if (__all(ok)) break;
-                    if (!spin_alive(spins, kn, &hdr->err, kStatusHandoff)) {  // wave-uniform
-                        s_dead = 1;
+                    if (++spins > kSpinLimit) {
+                        if (lane == 0) atomicOr(&hdr->err, 1u);
                         break;
                     }
                 }
@@ -527,7 +476,6 @@ __global__ __launch_bounds__(kXT) void fps_xcd_kernel(const float* __restrict__ 
             STAMP(4);
             lds_barrier();
             STAMP(5);
-            if (s_dead) return;
             k = s_win[buf];
             nx = s_wxyz[buf][0];
             ny = s_wxyz[buf][1];
@@ -595,8 +543,8 @@ __global__ __launch_bounds__(kXT) void fps_xcd_kernel(const float* __restrict__ 
                             const bool ok = ((v0 & kValid) != 0) & ((unsigned)(v1 >> 32) == tag) &
                                             ((unsigned)(v2 >> 32) == tag) & ((unsigned)(v3 >> 32) == tag);
                             if (ok) break;
-                            if (!spin_alive(spins, kn, &hdr->err, kStatusHandoff)) {
-                                s_dead = 1;
+                            if (++spins > kSpinLimit) {
+                                atomicOr(&hdr->err, 1u);
                                 v0 = kValid;
                                 break;
                             }
@@ -616,7 +564,6 @@ __global__ __launch_bounds__(kXT) void fps_xcd_kernel(const float* __restrict__ 
                 STAMP(4);
                 lds_barrier();
                 STAMP(5);
-                if (s_dead) return;
                 k = s_win[buf];
                 nx = s_wxyz[buf][0];
                 ny = s_wxyz[buf][1];
@@ -691,7 +638,7 @@ template <int PPT>
 __global__ __launch_bounds__(kXT) void fps_multi_kernel(const float* __restrict__ xyz, int64_t sb, int64_t sn, int64_t sc,
                                                         int B, int N, int npoint, const int64_t* __restrict__ start,
                                                         int32_t* __restrict__ out_idx, float* __restrict__ out_xyz,
-                                                        u64* gran, XcdHeader* hdr, int G, Knobs kn) {
+                                                        u64* gran, XcdHeader* hdr, int G) {
     constexpr int T = kXT, NW = T / 64;
     constexpr int kGran = 5;  // granules per member and round: {key, x, y, z} of its best point + the bound
     __shared__ u64 s_wkey[2][NW], s_wsec[2][NW];
@@ -703,9 +650,7 @@ __global__ __launch_bounds__(kXT) void fps_multi_kernel(const float* __restrict_
     __shared__ float s_px[PPT * kXT], s_py[PPT * kXT], s_pz[PPT * kXT];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int b = blockIdx.x; b < B; b += gridDim.x) poison_rows(out_idx, out_xyz, (size_t)b * npoint, npoint, tid, T);
-    __syncthreads();   // every store of the fill has left before thread 0's release + arrival in xcd_roles
-    if (tid == 0) xcd_roles(hdr, G, s_role, kn);
+    if (tid == 0) xcd_roles(hdr, G, s_role);
     __syncthreads();
     const int group = s_role[0], g = s_role[1], ngroups = s_role[2];
     const bool local = s_role[3] != 0;
@@ -837,7 +782,6 @@ __global__ __launch_bounds__(kXT) void fps_multi_kernel(const float* __restrict_
                 // ---- poll: lane l reads the five granules of members l and l + 64 (G <= 128)
                 u64 ek[2] = {0, 0}, hb = 0;
                 unsigned ex[2] = {0, 0}, ey[2] = {0, 0}, ez[2] = {0, 0};
-                bool dead = false;
                 {
                     const bool two = G > 64;  // wave-uniform
                     const u64* src0 = slot + (lane < G ? lane : 0);
@@ -863,8 +807,8 @@ __global__ __launch_bounds__(kXT) void fps_multi_kernel(const float* __restrict_
                             ex[1] = (unsigned)w1, ey[1] = (unsigned)w2, ez[1] = (unsigned)w3;
                         }
                         if (__all(ok)) break;
-                        if (!spin_alive(spins, kn, &hdr->err, kStatusHandoff)) {  // wave-uniform
-                            dead = true;   // reported to the whole workgroup through s_m below
+                        if (++spins > kSpinLimit) {
+                            if (lane == 0) atomicOr(&hdr->err, 1u);
                             break;
                         }
                     }
@@ -912,19 +856,18 @@ __global__ __launch_bounds__(kXT) void fps_multi_kernel(const float* __restrict_
                     if (keep) acc = t + 1;
                 }
                 if (acc > npoint - count) acc = npoint - count;
-                if (g == 0 && lane < acc && !dead) {
+                if (g == 0 && lane < acc) {
                     const size_t o = (size_t)b * npoint + count + lane;
                     out_idx[o] = (int)(0xFFFFFFFFu - (unsigned)(s_ckey[buf][lane] & 0xFFFFFFFFull));
                     if (out_xyz)
                         out_xyz[o * 3] = s_cent[buf][lane][0], out_xyz[o * 3 + 1] = s_cent[buf][lane][1],
                                     out_xyz[o * 3 + 2] = s_cent[buf][lane][2];
                 }
-                if (lane == 0) s_m[buf] = dead ? -1 : acc;   // -1: the launch is dead, everybody leaves after the barrier
+                if (lane == 0) s_m[buf] = acc;
             }
             STAMP(5);  // group list + chain (wave 0) / wait (others)
             lds_barrier();
             m = s_m[buf];
-            if (m < 0) return;    // dead launch (uniform: every thread reads the same word after the same barrier)
 #pragma unroll
             for (int t = 0; t < kMK; ++t) ccx[t] = s_cent[buf][t][0], ccy[t] = s_cent[buf][t][1], ccz[t] = s_cent[buf][t][2];
             count += m;
@@ -1002,26 +945,10 @@ Config pick(int B, int N) {
 
 template <int PPT, int T>
 void launch(const Config& c, const float* xyz, int64_t sb, int64_t sn, int64_t sc, int B, int N, int npoint,
-            const int64_t* start, int32_t* out_idx, float* out_xyz, u64* gran, unsigned* err, const Knobs& kn, hipStream_t s,
-            const int* coff = nullptr) {
-    if (c.G > 1)
-        PN2_LAUNCH("fps", (double)B * (12.0 * N + 8.0 * npoint), 0, (fps_kernel<PPT, T, true>), dim3(c.groups * c.G), dim3(T), s, xyz,
-                   sb, sn, sc, B, N, npoint, start, out_idx, out_xyz, gran, err, c.G, c.groups, kn, coff);
-    else if (coff)
-        PN2_LAUNCH("fps", (double)B * (12.0 * N + 8.0 * npoint), 0, (fps_kernel<PPT, T, false, true>), dim3(c.groups * c.G), dim3(T), s,
-                   xyz, sb, sn, sc, B, N, npoint, start, out_idx, out_xyz, gran, err, c.G, c.groups, kn, coff);
-    else
-        PN2_LAUNCH("fps", (double)B * (12.0 * N + 8.0 * npoint), 0, (fps_kernel<PPT, T, false>), dim3(c.groups * c.G), dim3(T), s, xyz,
-                   sb, sn, sc, B, N, npoint, start, out_idx, out_xyz, gran, err, c.G, c.groups, kn, coff);
+            const int64_t* start, int32_t* out_idx, float* out_xyz, u64* gran, unsigned* err, hipStream_t s) {
+    PN2_LAUNCH("fps", (double)B * (12.0 * N + 8.0 * npoint), 0, (fps_kernel<PPT, T>), dim3(c.groups * c.G), dim3(T), s, xyz, sb,
+               sn, sc, B, N, npoint, start, out_idx, out_xyz, gran, err, c.G, c.groups);
 }
-
-Knobs knobs(int32_t* status) {
-    Knobs kn{kSpinLimitDefault, 0, status};
-    if (const char* e = getenv("PN2_FPS_SPIN_LIMIT")) kn.spin_limit = (unsigned)strtoul(e, nullptr, 10);   // test aid
-    kn.force_fallback = getenv("PN2_FPS_FORCE_FALLBACK") != nullptr;
-    return kn;
-}
-
 
 }  // namespace
 
@@ -1039,9 +966,8 @@ extern "C" size_t pn2_fps_workspace_bytes(int B, int N, int npoint) {
 
 extern "C" int pn2_fps_f32(const float* xyz, int64_t sb, int64_t sn, int64_t sc, int B, int N, int npoint,
                            const int64_t* start, int32_t* out_idx, float* out_xyz, void* workspace,
-                           size_t workspace_bytes, int32_t* status, void* stream) {
+                           size_t workspace_bytes, void* stream) {
     if (!xyz || !start || !out_idx || !workspace || B <= 0 || N <= 0 || npoint <= 0) return PN2_E_BADARG;
-    const Knobs kn = knobs(status);
     if (use_xcd_kernel(N)) {
         const size_t need = pn2_fps_workspace_bytes(B, N, npoint);
         if (workspace_bytes < need) return PN2_E_WORKSPACE;
@@ -1054,20 +980,20 @@ extern "C" int pn2_fps_f32(const float* xyz, int64_t sb, int64_t sn, int64_t sc,
             const double fb = (double)B * (12.0 * N + 8.0 * npoint);
             if (ppt == 4)
                 PN2_LAUNCH("fps", fb, 0, (fps_multi_kernel<4>), dim3(kXGrid), dim3(kXT), s, xyz, sb, sn, sc, B, N, npoint, start,
-                           out_idx, out_xyz, gran, hdr, G, kn);
+                           out_idx, out_xyz, gran, hdr, G);
             else if (ppt == 8)
                 PN2_LAUNCH("fps", fb, 0, (fps_multi_kernel<8>), dim3(kXGrid), dim3(kXT), s, xyz, sb, sn, sc, B, N, npoint, start,
-                           out_idx, out_xyz, gran, hdr, G, kn);
+                           out_idx, out_xyz, gran, hdr, G);
             else
                 PN2_LAUNCH("fps", fb, 0, (fps_multi_kernel<16>), dim3(kXGrid), dim3(kXT), s, xyz, sb, sn, sc, B, N, npoint, start,
-                           out_idx, out_xyz, gran, hdr, G, kn);
+                           out_idx, out_xyz, gran, hdr, G);
         }
         else if (xcd_perwave(N))
             PN2_LAUNCH("fps", (double)B * (12.0 * N + 8.0 * npoint), 0, (fps_xcd_kernel<true>), dim3(kXGrid), dim3(kXT), s, xyz, sb,
-                       sn, sc, B, N, npoint, start, out_idx, out_xyz, gran, hdr, xcd_group_size(N), kn);
+                       sn, sc, B, N, npoint, start, out_idx, out_xyz, gran, hdr, xcd_group_size(N));
         else
             PN2_LAUNCH("fps", (double)B * (12.0 * N + 8.0 * npoint), 0, (fps_xcd_kernel<false>), dim3(kXGrid), dim3(kXT), s, xyz, sb,
-                       sn, sc, B, N, npoint, start, out_idx, out_xyz, gran, hdr, xcd_group_size(N), kn);
+                       sn, sc, B, N, npoint, start, out_idx, out_xyz, gran, hdr, xcd_group_size(N));
         PN2_LAUNCH_CHECK();
         return 0;
     }
@@ -1079,54 +1005,9 @@ extern "C" int pn2_fps_f32(const float* xyz, int64_t sb, int64_t sn, int64_t sc,
     PN2_HIP_CHECK(hipMemsetAsync(workspace, 0, need, s));
     unsigned* err = (unsigned*)workspace;
     u64* gran = (u64*)((char*)workspace + kHdr);
-    if (c.G > 1) {   // consecutive-block groups have no arrival phase to order an in-kernel fill: two memset nodes
-        PN2_HIP_CHECK(hipMemsetAsync(out_idx, 0xFF, (size_t)B * npoint * sizeof(int32_t), s));
-        if (out_xyz) PN2_HIP_CHECK(hipMemsetAsync(out_xyz, 0xFF, (size_t)B * npoint * 3 * sizeof(float), s));
-    }
 #define PN2_FPS_CASE(P, T_)                                                                                  \
     if (c.ppt == P && c.t == T_) {                                                                           \
-        launch<P, T_>(c, xyz, sb, sn, sc, B, N, npoint, start, out_idx, out_xyz, gran, err, kn, s);          \
-    } else
-    PN2_FPS_CASE(1, 256)
-    PN2_FPS_CASE(2, 256)
-    PN2_FPS_CASE(4, 256)
-    PN2_FPS_CASE(8, 256)
-    PN2_FPS_CASE(16, 256)
-    PN2_FPS_CASE(4, 1024)
-    PN2_FPS_CASE(8, 1024)
-    PN2_FPS_CASE(16, 512)
-    PN2_FPS_CASE(32, 512) { return PN2_E_BADARG; }
-#undef PN2_FPS_CASE
-    PN2_LAUNCH_CHECK();
-    return 0;
-}
-
-// Ragged batch of small clouds (every cloud <= 16384 points: one workgroup each, no hand-off, nothing to time out).
-// N_max picks the points-per-lane configuration; clouds shorter than that leave lanes idle.
-extern "C" size_t pn2_fps_ragged_workspace_bytes(int C, int n_max, int npoint) {
-    if (C <= 0 || n_max <= 0 || n_max > 32 * 512 || npoint <= 0) return 0;
-    return kHdr;
-}
-
-extern "C" int pn2_fps_ragged_f32(const float* xyz_cf, const int32_t* coff, int C, int n_max, int npoint, const int64_t* start,
-                                  int32_t* out_idx, float* out_xyz, void* workspace, size_t workspace_bytes, void* stream) {
-    if (!xyz_cf || !coff || !start || !out_idx || !workspace || C <= 0 || n_max <= 0 || n_max > 32 * 512 || npoint <= 0)
-        return PN2_E_BADARG;
-    if (workspace_bytes < kHdr) return PN2_E_WORKSPACE;
-    hipStream_t s = (hipStream_t)stream;
-    // one member per cloud: the smallest (points per lane x threads) that covers the longest cloud
-    static const int cand[][2] = {{1, 256}, {2, 256}, {4, 256}, {8, 256}, {16, 256}, {4, 1024}, {8, 1024}, {16, 512}, {32, 512}};
-    Config c{0, 0, 1, C < 256 ? C : 256, 0.0};
-    for (auto& k : cand)
-        if (k[0] * k[1] >= n_max) {
-            if (!c.ppt || 0.02 * k[0] + 0.0004 * k[1] < 0.02 * c.ppt + 0.0004 * c.t) c.ppt = k[0], c.t = k[1];
-        }
-    if (!c.ppt) return PN2_E_BADARG;
-    const Knobs kn = knobs(nullptr);
-    unsigned* err = (unsigned*)workspace;
-#define PN2_FPS_CASE(P, T_)                                                                                              \
-    if (c.ppt == P && c.t == T_) {                                                                                       \
-        launch<P, T_>(c, xyz_cf, 0, 1, 0, C, n_max, npoint, start, out_idx, out_xyz, nullptr, err, kn, s, (const int*)coff); \
+        launch<P, T_>(c, xyz, sb, sn, sc, B, N, npoint, start, out_idx, out_xyz, gran, err, s);              \
     } else
     PN2_FPS_CASE(1, 256)
     PN2_FPS_CASE(2, 256)

@@ -1,0 +1,217 @@
+/*
+ * pn2_hip.h -- C ABI of libpn2hip.so, the MI355X (gfx950) implementation of the PointNet++ hot path.
+ *
+ * The reference has no FFI boundary of its own for this path: the boundary is the Python API of
+ * Modules/PointNet2/pointnet2_utils.py and blocks.py.  Each entry point below replaces the
+ * device work of one reference expression group; the Python mirror that keeps the reference's signatures
+ * (extracting-tree-morphology-from-point-clouds_amd/PointNet2/) binds these symbols with ctypes, and
+ * INTEGRATION.md shows the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into caller-owned memory; the library never allocates, frees or
+ *     synchronises.  Work is enqueued on `stream` (a hipStream_t passed as void*).
+ *   - return value: 0 ok; negative = rejected arguments (PN2_E_*); positive = hipError_t of a failed launch.
+ *   - coordinates/features are addressed as base + b*sb + n*sn + c*sc (strides in ELEMENTS), so both the
+ *     reference's [B,N,3] tensors and permuted views of its channel-first [B,3,N] tensors are accepted
+ *     without a copy.  Outputs are dense row-major.
+ *   - indices are int32 on the device side (the Python mirror widens to torch.long where the reference
+ *     API returns it).
+ *   - all arithmetic is fp32 with the operation order of the reference's CPU path (see oracle/pn2_oracle.c).
+ */
+#ifndef PN2_HIP_H
+#define PN2_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PN2_E_BADARG (-1)   /* null pointer / non-positive size / unsupported size */
+#define PN2_E_WORKSPACE (-2) /* workspace too small */
+
+#define PN2_ABI_VERSION 1
+
+/* ABI version of the loaded library (compare with PN2_ABI_VERSION). */
+int pn2_version(void);
+
+/* Static description of the code object, e.g. "gfx950". */
+const char *pn2_arch(void);
+
+/* ---------------------------------------------------------------------------------------------------
+ * square_distance                  replaces Modules/PointNet2/pointnet2_utils.py:21-42
+ *   out [B,N,M] = ((-2 * src.dst) + |src|^2) + |dst|^2, the reference's expansion (not the direct distance).
+ *   API completeness only: ball query and three_nn evaluate the same expression without materialising it.
+ */
+int pn2_square_distance_f32(const float *src, int64_t ab, int64_t an, int64_t ac, const float *dst, int64_t bb,
+                            int64_t bn, int64_t bc, int B, int N, int M, float *out, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * farthest_point_sample            replaces Modules/PointNet2/pointnet2_utils.py:66-89
+ *   start    [B] int64   first centroid per cloud (the reference's torch.randint draw, line 79)
+ *   out_idx  [B,npoint] int32
+ *   out_xyz  [B,npoint,3] f32 or NULL -- the gathered centroids (index_points(xyz, idx), line 154)
+ *   workspace: pn2_fps_workspace_bytes(B,N,npoint) bytes, contents irrelevant on entry.
+ */
+size_t pn2_fps_workspace_bytes(int B, int N, int npoint);
+int pn2_fps_f32(const float *xyz, int64_t sb, int64_t sn, int64_t sc, int B, int N, int npoint,
+                const int64_t *start, int32_t *out_idx, float *out_xyz, void *workspace,
+                size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * query_ball_point                 replaces Modules/PointNet2/pointnet2_utils.py:92-136
+ *   r2       float32(double(radius)**2); a point is inside unless d > r2
+ *   out_idx  [B,S,Keff] int32, Keff = min(nsample, N): first Keff inside indices ascending, short rows
+ *            padded with their first entry, empty balls filled with argmin of the row.
+ *   workspace: pn2_ball_query_workspace_bytes(B,N,S,nsample) bytes.
+ */
+size_t pn2_ball_query_workspace_bytes(int B, int N, int S, int nsample);
+int pn2_ball_query_f32(const float *xyz, int64_t sb, int64_t sn, int64_t sc, const float *new_xyz,
+                       int64_t qb, int64_t qn, int64_t qc, int B, int N, int S, float r2, int nsample,
+                       int32_t *out_idx, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * group_points (+ centring + concat)   replaces index_points x2 and lines 156-161 of sample_and_group
+ *   out [B,S,K,3+D]: channels [xyz - new_xyz, feats] or, with xyz_last != 0, [feats, xyz - new_xyz]
+ *   (the MSG order, blocks.py:143-146).  feats may be NULL with D = 0.
+ */
+int pn2_group_f32(const float *xyz, int64_t sb, int64_t sn, int64_t sc, const float *new_xyz,
+                  const float *feats, int64_t fb, int64_t fn, int64_t fc, const int32_t *idx, int B, int N,
+                  int S, int K, int D, int xyz_last, float *out, void *stream);
+
+/* gradient w.r.t. feats: dfeats [B,N,D] (dense, zeroed by the call) += dout[..., feature channels] */
+int pn2_group_grad_f32(const float *dout, const int32_t *idx, int B, int N, int S, int K, int D,
+                       int xyz_last, float *dfeats, void *stream);
+
+/* plain index_points: out[b][s][:] = points[b][idx[b][s]][:]   (pointnet2_utils.py:45-63) */
+int pn2_gather_f32(const float *points, int64_t pb, int64_t pn, int64_t pc, const int32_t *idx, int B, int N,
+                   int S, int C, float *out, void *stream);
+int pn2_gather_grad_f32(const float *dout, const int32_t *idx, int B, int N, int S, int C, float *dpoints,
+                        void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * three_nn                          replaces Modules/PointNet2/blocks.py:194-203
+ *   for every xyz1 point the 3 smallest square_distance(xyz1, xyz2) entries, ties -> lower index first;
+ *   out_idx [B,N,3] int32, out_w [B,N,3] normalised inverse-distance weights, out_dist [B,N,3] or NULL.
+ *   Requires S >= 3.
+ */
+int pn2_three_nn_f32(const float *xyz1, int64_t ab, int64_t an, int64_t ac, const float *xyz2, int64_t bb,
+                     int64_t bn, int64_t bc, int B, int N, int S, int32_t *out_idx, float *out_w,
+                     float *out_dist, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * masked point-wise loss            replaces the arithmetic of Modules/Loss.py:6-36 (point_wise_loss) under the masks
+ *                                   of Modules/PointNet2/PointNet2.py:180-207 (get_loss)
+ *   sem [R,2], off [R,3] predictions of the padded rows; pad / off_mask [R] (1 byte each); cum_pad / cum_off [R]
+ *   inclusive int64 prefix sums of the masks (cum - 1 = the row's position in the compacted label arrays sem_labels
+ *   [n_sem] int64, off_labels [n_off,3]).  out2 = {sum_pad CE / max(n_valid,1), sum_offmask sqrt(max(|d|^2,1e-8)) /
+ *   max(n_off_rows,1)}.  Backward: grad2 = d/d out2 -> dsem [R,2], doff [R,3] (zero on masked-out rows).
+ */
+size_t pn2_point_loss_workspace_bytes(int R);
+int pn2_point_loss_fwd_f32(const float *sem, const float *off, const unsigned char *pad, const unsigned char *off_mask,
+                           const int64_t *cum_pad, const int64_t *cum_off, const int64_t *sem_labels, int64_t n_sem,
+                           const float *off_labels, int64_t n_off, int R, float *out2, void *workspace,
+                           size_t workspace_bytes, void *stream);
+int pn2_point_loss_bwd_f32(const float *sem, const float *off, const unsigned char *pad, const unsigned char *off_mask,
+                           const int64_t *cum_pad, const int64_t *cum_off, const int64_t *sem_labels, int64_t n_sem,
+                           const float *off_labels, int64_t n_off, int R, const float *grad2, float *dsem, float *doff,
+                           void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * kNN feature helpers               replaces the neighbourhood work of Modules/Features.py:111-175
+ *   (compute_normals_ckdtree :111-133, compute_curvature_ckdtree :136-158, compute_density_ckdtree :161-173,
+ *    as driven by add_features :178-229).  float64 like the reference.
+ *   pn2_knn_radius_f64: points [N][3] contiguous; nn_idx [N][k] int32 = the k nearest points of every point,
+ *     ascending by (squared distance, index) -- the point itself first, like cKDTree.query(points, k);
+ *     nn_d2 [N][k] squared distances or NULL; radius_count [N] = number of points with d^2 <= r2 (the point
+ *     itself included, like len(tree.query_ball_point(p, r))) or NULL.  k <= 16.
+ *   pn2_cov_eig_f64: for every point the np.cov (unbiased) covariance of the offsets to its first k neighbours
+ *     (rows of nn_idx, k_stride entries apart), evals [N][3] ascending, evecs [N][3][3]: row r = unit eigenvector of
+ *     evals[r], sign fixed so that its largest component is positive.
+ */
+int pn2_knn_radius_f64(const double *points, int N, int k, double r2, int32_t *nn_idx, double *nn_d2,
+                       int32_t *radius_count, void *stream);
+int pn2_cov_eig_f64(const double *points, int N, const int32_t *nn_idx, int k_stride, int k, double *evals,
+                    double *evecs, void *stream);
+/* Same contract and bit-identical results through a hashed cell grid (csrc/knn_grid.hip): the cloud is binned into
+ * cells (adaptive edge), every query's 27 surrounding cells are searched by one wavefront and certified against the
+ * cell edge; queries the grid cannot settle are redone by a full scan.  radius_count uses a second grid whose edge is
+ * the radius (r2 < 0 or radius_count == NULL: no count).  workspace: pn2_knn_grid_workspace_bytes(N) bytes. */
+size_t pn2_knn_grid_workspace_bytes(int N);
+int pn2_knn_radius_grid_f64(const double *points, int N, int k, double r2, int32_t *nn_idx, double *nn_d2,
+                            int32_t *radius_count, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * three_interpolate                 replaces Modules/PointNet2/blocks.py:204
+ *   points2 [B,S,D] (strided), out rows of out_stride floats; the D interpolated channels are written at
+ *   column out_offset (so the skip-connection concat of blocks.py:208 needs no extra copy).
+ */
+int pn2_three_interpolate_f32(const float *points2, int64_t pb, int64_t pn, int64_t pc, const int32_t *idx,
+                              const float *w, int B, int N, int S, int D, float *out, int64_t out_stride,
+                              int64_t out_offset, void *stream);
+/* dpoints2 [B,S,D] (dense, zeroed by the call) += w * dout[:, out_offset : out_offset+D]
+ * workspace: pn2_three_interpolate_grad_workspace_bytes(B,N,S,D) bytes (large calls bucket the contributions by
+ * destination before summing them). */
+size_t pn2_three_interpolate_grad_workspace_bytes(int B, int N, int S, int D);
+int pn2_three_interpolate_grad_f32(const float *dout, int64_t out_stride, int64_t out_offset,
+                                   const int32_t *idx, const float *w, int B, int N, int S, int D,
+                                   float *dpoints2, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Pointwise MLP chains: (1x1 conv -> BatchNorm -> ReLU) x n [-> max over groups of pool_k rows]
+ *   replaces the Conv2d/BatchNorm2d/ReLU/max stack of Modules/PointNet2/blocks.py:93-98 (set abstraction),
+ *   the Conv1d/BatchNorm1d/ReLU stack of :213-215 (feature propagation) and ConvHead :7-35, fwd and bwd.
+ *
+ * Activations are channels-last rows: x [rows][cin_0] with row stride ldx.  Layer i computes
+ *   y_i = act_{i-1} W_i^T + b_i,   act_i = relu?(BatchNorm(y_i))  (train: batch statistics over all rows,
+ *   running stats updated like nn.BatchNorm; eval: running stats),
+ * y_i (pre-BatchNorm) is kept in layers[i].y for the backward pass and the normalised activation is never
+ * written except for the chain's output:
+ *   pool_k <= 1: out [rows][cout_last] = act_last        (a last layer without BatchNorm writes y itself)
+ *   pool_k  > 1: out [rows/pool_k][cout_last] = max over each group of pool_k consecutive rows, pool_arg
+ *                [rows/pool_k][cout_last] int32 = first row offset attaining it (torch.max's choice).
+ * stats: [8][cout] floats per BatchNorm layer (mean, biased var, invstd, gamma*invstd, beta, and two rows
+ * written by the backward pass); running_mean/var may be NULL (no tracking).
+ *
+ * Backward: dout has the shape of out; gradients are ACCUMULATED (+=) into dweight/dbias/dgamma/dbeta where
+ * non-NULL (dbias of a conv feeding a BatchNorm is analytically zero and is left untouched); dx [rows][cin_0]
+ * (row stride lddx) is written when non-NULL.  scratch_a/b: two buffers of rows * max(cin_i, cout_last) floats.
+ * workspace: pn2_mlp_workspace_bytes(rows, layers, nlayers) bytes for either direction.
+ */
+typedef struct pn2_mlp_layer {
+    int32_t cin, cout;
+    const float *weight;       /* [cout][cin] */
+    const float *bias;         /* [cout] or NULL */
+    int32_t has_bn, relu;
+    const float *gamma, *beta; /* [cout] or NULL (1, 0) */
+    float *running_mean, *running_var;
+    float eps, momentum;
+    float *y;                  /* [rows][cout] pre-BatchNorm output (written by fwd, read by bwd) */
+    float *stats;              /* [8][cout] */
+    float *dweight, *dbias, *dgamma, *dbeta;
+} pn2_mlp_layer;
+
+size_t pn2_mlp_workspace_bytes(int rows, const pn2_mlp_layer *layers, int nlayers);
+int pn2_mlp_chain_fwd_f32(const float *x, int64_t ldx, int rows, const pn2_mlp_layer *layers, int nlayers,
+                          int training, int pool_k, float *out, int32_t *pool_arg, void *workspace,
+                          size_t workspace_bytes, void *stream);
+int pn2_mlp_chain_bwd_f32(const float *x, int64_t ldx, int rows, const pn2_mlp_layer *layers, int nlayers,
+                          int pool_k, const float *dout, const int32_t *pool_arg, float *dx, int64_t lddx,
+                          float *scratch_a, float *scratch_b, void *workspace, size_t workspace_bytes,
+                          void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Measurement hook (bench.py): with profiling enabled every kernel launch of the library is bracketed by two
+ * HIP events on its launch stream.  pn2_prof_collect synchronises on them, aggregates by (kernel name,
+ * algorithmic bytes, flops) of a launch, writes NUL-separated names and per-group totals, clears the records and
+ * returns the number of groups.  Not meant to be left on in production (it creates two events per launch).
+ */
+void pn2_prof_enable(int on);
+int pn2_prof_collect(char *names_buf, size_t names_cap, double *total_ms, long long *calls, double *bytes,
+                     double *flops, int max_groups);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PN2_HIP_H */
