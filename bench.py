@@ -207,8 +207,9 @@ def main():
 
     torch.manual_seed(0)                                  # identical random-init weights on every rank
     model = PointNet2(depth=depth, loss_multiplier_semantic=0).to(dev).train()
-    grads = parallel.FlatGradAllReduce(model)
-    opt = torch.optim.AdamW(model.parameters(), lr=0.01, weight_decay=1e-3, fused=True)   # train_PointNet2.py:250
+    # parameters and gradients live in two flat, 16-byte-aligned buffers: one all-reduce and ONE fused AdamW launch per step
+    grads = parallel.FlatGradAllReduce(model, flatten_params=True)
+    opt = torch.optim.AdamW([grads.flat_param], lr=0.01, weight_decay=1e-3, fused=True)   # train_PointNet2.py:250
     if rasterized:
         stream, labels, padded, n_rasters = make_raster_stream(args.points, seed=rank, device=dev)
     else:

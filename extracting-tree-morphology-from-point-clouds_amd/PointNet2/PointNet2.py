@@ -14,6 +14,7 @@ import torch.nn.functional as F
 
 from .. import ops, streaming
 from ..Loss import MaskedPointLoss, point_wise_loss
+from ..mlp import batched_counters
 from ..Utils import cuda_cast
 from .blocks import (MLP, ConvHead, PointNetFeaturePropagation, PointNetSetAbstraction,
                      PointNetSetAbstractionMsg)
@@ -80,9 +81,10 @@ class PointNet2(nn.Module):
     def forward(self, batch, return_loss):
         """batch: coords [B,3,N], feats [B,F,N] (+ masks/labels when return_loss).  Reference lines 118-134."""
         output = dict()
-        output["backbone_feats"] = self.forward_backbone(coords=batch["coords"], feats=batch["feats"])
-        output["semantic_prediction_logits"] = self.semantic_linear(output["backbone_feats"])
-        output["offset_predictions"] = self.offset_linear(output["backbone_feats"])
+        with batched_counters():        # one launch for all BatchNorm step counters of the pass
+            output["backbone_feats"] = self.forward_backbone(coords=batch["coords"], feats=batch["feats"])
+            output["semantic_prediction_logits"] = self.semantic_linear(output["backbone_feats"])
+            output["offset_predictions"] = self.offset_linear(output["backbone_feats"])
         if return_loss:
             output = self.get_loss(model_output=output, **batch)
         return output

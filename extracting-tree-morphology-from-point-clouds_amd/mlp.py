@@ -179,6 +179,26 @@ class _ChainFn(torch.autograd.Function):
         return (dx, None, *grads)
 
 
+class batched_counters:
+    """Context: collect the `num_batches_tracked` bumps of every chain called inside and apply them with ONE
+    torch._foreach_add_ at exit (a forward pass of the depth-4 model otherwise issues ten of those tiny launches)."""
+    active = None
+
+    def __enter__(self):
+        self.outer, self.pending = batched_counters.active, []
+        batched_counters.active = self
+        return self
+
+    def __exit__(self, *exc):
+        batched_counters.active = self.outer
+        if self.pending:
+            by_inc = {}
+            for t, inc in self.pending:
+                by_inc.setdefault(inc, []).append(t)
+            for inc, ts in by_inc.items():
+                torch._foreach_add_(ts, inc)
+
+
 def chain_rows(x, layers, pool_k=1, seg_off=None, dx_first_col=0):
     """x [R, C_in] fp32 rows; layers: iterable of (conv, bn_or_None, relu: bool).
     -> [R, C_out], or [R // pool_k, C_out] (max over each group of pool_k consecutive rows) when pool_k > 1.
@@ -218,5 +238,9 @@ def chain_rows(x, layers, pool_k=1, seg_off=None, dx_first_col=0):
         meta["seg_off"] = [int(v) for v in seg_off]
         nseg = len(seg_off) - 1
     if bump:
-        torch._foreach_add_(bump, nseg if training else 1)
+        inc = nseg if training else 1
+        if batched_counters.active is not None:
+            batched_counters.active.pending += [(t, inc) for t in bump]
+        else:
+            torch._foreach_add_(bump, inc)
     return _ChainFn.apply(x, meta, *params)

@@ -27,7 +27,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _hip, ops
-from .mlp import chain_rows
+from .mlp import batched_counters, chain_rows
 from .PointNet2.blocks import PointNetSetAbstractionMsg, _group_mlp_max
 
 MAX_ROWS_PER_PASS = 6_000_000       # level-0 rows (padded points) per pass: ~60 GB of activations at depth 5
@@ -161,7 +161,7 @@ def backbone_and_heads(model, layout, device):
     starts = [s.pin_memory().to(device, non_blocking=True) for s in draw_starts(layout, model)]
     sas = _sa_modules(model)
     n = len(sas)
-    with torch.amp.autocast("cuda", enabled=False):
+    with torch.amp.autocast("cuda", enabled=False), batched_counters():
         xyz, pts = [None], [None]
         for lvl, sa in enumerate(sas):
             nx, npts = _sa_level(sa, xyz[-1], pts[-1], starts[lvl], layout, rc=rc if lvl == 0 else None)

@@ -70,7 +70,7 @@ def worker(rank, world, port, out):
         (loss * (b - a) / (hi - lo)).backward()
     sync.allreduce()
     assert calls["n"] == 1
-    grad = sync.flat.clone()
+    grad = sync.packed()
     opt.step()
     params = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
     gathered = [torch.zeros_like(params) for _ in range(world)]

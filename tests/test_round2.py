@@ -376,9 +376,9 @@ def _dp_worker(rank, world, port, n, trees, depth, q):
     ops.check_status()
     # numpy, not tensors: torch shares tensor storage through file descriptors that die with this process
     if rank == 0:
-        q.put(([p.detach().cpu().numpy() for p in model.parameters()], sync.flat.cpu().numpy(), float(loss)))
+        q.put(([p.detach().cpu().numpy() for p in model.parameters()], sync.packed().cpu().numpy(), float(loss)))
     else:
-        q.put((None, sync.flat.cpu().numpy(), float(loss)))
+        q.put((None, sync.packed().cpu().numpy(), float(loss)))
     dist.barrier()
     dist.destroy_process_group()
 
