@@ -524,6 +524,57 @@ def test_forward_hierarchical_streaming_golden(pn2, mode, monkeypatch):
     assert float(pred["offset_predictions"][torch.from_numpy(~visited).cuda()].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("mode", ["fused", "sequential"])
+def test_forward_hierarchical_golden(pn2, mode, monkeypatch):
+    """PointNet2.forward_hierarchical (the NON-streaming raster mode, reference PointNet2.py:329-394): predictions are
+    accumulated WITH autograd history, averaged per point id, ONE loss over the whole cloud (unvisited points predict
+    zero), one backward.  Fixture: the reference's own method on the streaming fixture's tree
+    (tests/golden/make_golden_hier.py); both execution modes."""
+    monkeypatch.setenv("PN2_STREAMING", mode)
+    from pn2_amd.PointNet2.PointNet2 import PointNet2
+    from pn2_amd.synthetic import gaussian_branch_tree
+    g, gs = gold("hierarchical_d5.npz"), gold("streaming_d5.npz")
+    xyz, off, _ = gaussian_branch_tree(20000, seed=5)
+    n = len(xyz)
+    feats_all = (np.sin(0.61 * np.arange(n * 4, dtype=np.float64) + 7)).astype(np.float32).reshape(n, 4)
+    rasters = [gs[f"raster{i}"].astype(np.int64) for i in range(int(gs["n_rasters"]))]
+    mbs = []
+    for k in range(0, len(rasters), 2):
+        group = rasters[k:k + 2]
+        nmax = max(len(r) for r in group)
+        coords = np.zeros((len(group), 3, nmax), np.float32)
+        fts = np.zeros((len(group), 4, nmax), np.float32)
+        mpad = np.zeros((len(group), nmax), bool)
+        for i, r in enumerate(group):
+            coords[i, :, :len(r)] = (xyz[r] - np.floor(xyz[r].min(axis=0))).T
+            fts[i, :, :len(r)] = feats_all[r].T
+            mpad[i, :len(r)] = True
+        ids = np.concatenate(group)
+        mbs.append({"coords": dev(coords), "feats": dev(fts), "masks_pad": dev(mpad), "masks_off": dev((np.arange(len(ids)) % 5) != 2),
+                    "point_ids": dev(ids)})
+    torch.manual_seed(20250718)
+    model = PointNet2(depth=5).cuda().train()
+    batch = {"cloud_length": n, "mini_batches": iter(mbs), "semantic_labels": torch.from_numpy((np.arange(n) % 3 == 0).astype(np.int64))[:, None],
+             "offset_labels": torch.from_numpy(off)}
+    torch.manual_seed(41)
+    loss, ld = model.forward_hierarchical(batch, return_loss=True)
+    loss.backward()
+    for key, val in (("loss", loss), ("offset_loss", ld["offset_loss"]), ("semantic_loss", ld["semantic_loss"])):
+        assert abs(float(val.detach()) - float(g[key + "_f64"])) <= 2e-4 * abs(float(g[key + "_f64"])), key
+    params = dict(model.named_parameters())
+    gmax = float(g["grad_l2_f64"].max())
+    noise = max(abs(l2 - l64) / l64 for n_, l2, l64 in zip(g["grad_names"], g["grad_l2"], g["grad_l2_f64"])
+                if not helpers.is_pre_bn_bias(str(n_)) and l64 > 1e-3 * gmax)
+    print(f"hierarchical ({mode}): reference fp32 gradient-norm noise level {noise:.2e}")
+    for name, l2, l64 in zip(g["grad_names"], g["grad_l2"], g["grad_l2_f64"]):
+        name = str(name)
+        if helpers.is_pre_bn_bias(name):
+            continue
+        got = float(params[name].grad.double().norm())
+        bar = max(5e-4 * l64, 2 * noise * l64, 3 * abs(l2 - l64)) + 1e-6 * gmax
+        assert abs(got - l64) <= bar, f"grad norm of {name}: {got} vs {l64}"
+
+
 def test_get_loss_matches_compacted_form(pn2):
     """The sync-free masked loss of PointNet2.get_loss equals point_wise_loss on the compacted rows (the reference's
     formulation, PointNet2.py:180-207) for values and for the gradients w.r.t. the predictions."""
