@@ -185,12 +185,19 @@ __global__ __launch_bounds__(kBlock) void three_interpolate_kernel(const float* 
 
 // Backward of the interpolation: dpoints2[b][idx[n][k]][c] += w[n][k] * dout[n][c].  ~768 dense points feed every
 // sampled point at FP1; issued as 3*N*D float atomics (100 M of them onto 512 KB) the op runs at the memory-side
-// atomic rate (0.5 ms), and LDS float atomics are no better (~2.6 LDS cycles per LANE, measured).  So the
-// contributions are first bucketed by destination (counting sort of the 3*N (point, weight) pairs: integer atomics
-// only), then one wavefront per 64-entry chunk of a destination's list sums the rows it names -- coalesced 512-byte
-// row reads, registers for the running sum -- and issues ONE float atomic row per chunk (64x fewer atomics).
+// atomic rate (0.5 ms), and LDS float atomics are no better (~2.6 LDS cycles per LANE, measured).  A full bucketing of
+// the 3*N (row, weight) pairs by destination (round 1) removes the atomics but reads every `dout` row three times
+// (PMC: 410 MB against 144 MB algorithmic).  Now the rows are bucketed by their NEAREST sampled point only (counting
+// sort of N row ids: integer atomics only), one wavefront owns a 64-row chunk of a bucket and reads each of its rows
+// ONCE (coalesced 512-byte rows, lane = channel):
+//   * the nearest-neighbour term accumulates in registers;
+//   * the second and third neighbours of the rows of one bucket are a handful of adjacent sampled points: they
+//     accumulate in a per-wavefront LDS table of TIG_SLOTS rows, slot = position of the destination in a lane-distributed
+//     tag list (one compare + ballot), lane-private read-modify-write, no atomics;
+//   * registers and slots are flushed with one float atomic row each per chunk (a destination beyond the table's
+//     capacity falls back to direct atomics).
 // Histogram of destinations.  Integer atomics on ~1000 hot global addresses serialise at ~235 ns each, so every
-// workgroup first counts its contiguous share of one cloud's pairs in LDS and then adds S totals to global memory.
+// workgroup first counts its contiguous share of one cloud's rows in LDS and then adds S totals to global memory.
 // blockIdx.y = cloud, blockIdx.x = share.
 constexpr int TIG_T = 1024;
 // the backward kernels see the indices the forward pass already validated (and flagged); clamping keeps a bad one from
@@ -202,12 +209,12 @@ __global__ __launch_bounds__(TIG_T) void tig_count_kernel(const int32_t* __restr
     const int b = blockIdx.y;
     const long long row0 = coff ? coff[b] : (long long)b * N;   // ragged batch: packed rows, n_b = coff[b+1] - coff[b]
     if (coff) N = coff[b + 1] - coff[b];
-    if ((long long)blockIdx.x * per_block >= 3LL * N) return;   // uniform
+    if ((long long)blockIdx.x * per_block >= N) return;         // uniform
     for (int e = threadIdx.x; e < S; e += TIG_T) lh[e] = 0;
     __syncthreads();
-    const long long p0 = (long long)blockIdx.x * per_block, p1 = p0 + per_block < 3LL * N ? p0 + per_block : 3LL * N;
+    const long long p0 = (long long)blockIdx.x * per_block, p1 = p0 + per_block < N ? p0 + per_block : N;
     const int32_t* ib = idx + row0 * 3;
-    for (long long e = p0 + threadIdx.x; e < p1; e += TIG_T) atomicAdd(&lh[clamp_idx(ib[e], S)], 1);
+    for (long long e = p0 + threadIdx.x; e < p1; e += TIG_T) atomicAdd(&lh[clamp_idx(ib[3 * e], S)], 1);
     __syncthreads();
     for (int e = threadIdx.x; e < S; e += TIG_T)
         if (lh[e]) atomicAdd(hist + (long long)b * S + e, lh[e]);
@@ -216,63 +223,84 @@ __global__ __launch_bounds__(TIG_T) void tig_count_kernel(const int32_t* __restr
 // exclusive scans over hist[0..total) (one block; total = B*S is a few thousand): offs = list offsets (cursor starts
 // as a copy), coffs = offsets in units of 64-entry chunks (what the reduce kernel's wavefronts index)
 constexpr int TIG_CHUNK = 64;
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(v, off, 64);
+        if (lane >= off) v += o;
+    }
+    return v;
+}
+// One block, 16 wavefronts: wavefront w owns a contiguous range of the histogram and walks it in 64-wide (coalesced)
+// tiles with a shuffle scan and a register carry -- no block barrier per tile; the 16 range totals are scanned once.
 __global__ __launch_bounds__(1024) void tig_scan_kernel(const int* __restrict__ hist, int total, int* __restrict__ offs,
                                                         int* __restrict__ cursor, int* __restrict__ coffs) {
-    __shared__ int part[1024], cpart[1024];
-    const int t = threadIdx.x;
-    const int per = (total + 1023) / 1024;
+    __shared__ int wsum[16], wcsum[16];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int per = ((total + 15) / 16 + 63) / 64 * 64;           // range length, a multiple of the tile
+    const int r0 = wv * per, r1 = r0 + per < total ? r0 + per : total;
     int sum = 0, csum = 0;
-    for (int k = 0; k < per; ++k) {
-        const int e = t * per + k;
-        if (e < total) {
-            sum += hist[e];
-            csum += (hist[e] + TIG_CHUNK - 1) / TIG_CHUNK;
-        }
+    for (int base = r0; base < r1; base += 64) {
+        const int e = base + lane;
+        const int h = e < r1 ? hist[e] : 0;
+        sum += h;
+        csum += (h + TIG_CHUNK - 1) / TIG_CHUNK;
     }
-    part[t] = sum;
-    cpart[t] = csum;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        sum += __shfl_xor(sum, off, 64);
+        csum += __shfl_xor(csum, off, 64);
+    }
+    if (lane == 0) {
+        wsum[wv] = sum;
+        wcsum[wv] = csum;
+    }
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        const int v = t >= off ? part[t - off] : 0, cv = t >= off ? cpart[t - off] : 0;
-        __syncthreads();
-        part[t] += v;
-        cpart[t] += cv;
-        __syncthreads();
+    int carry = 0, ccarry = 0;
+    for (int k = 0; k < wv; ++k) {
+        carry += wsum[k];
+        ccarry += wcsum[k];
     }
-    int run = t > 0 ? part[t - 1] : 0, crun = t > 0 ? cpart[t - 1] : 0;
-    for (int k = 0; k < per; ++k) {
-        const int e = t * per + k;
-        if (e < total) {
-            offs[e] = run;
-            cursor[e] = run;
-            coffs[e] = crun;
-            run += hist[e];
-            crun += (hist[e] + TIG_CHUNK - 1) / TIG_CHUNK;
+    for (int base = r0; base < r1; base += 64) {
+        const int e = base + lane;
+        const int h = e < r1 ? hist[e] : 0;
+        const int c = (h + TIG_CHUNK - 1) / TIG_CHUNK;
+        const int incl = wave_incl_scan(h, lane), cincl = wave_incl_scan(c, lane);
+        if (e < r1) {
+            offs[e] = carry + incl - h;
+            cursor[e] = carry + incl - h;
+            coffs[e] = ccarry + cincl - c;
         }
+        carry += __shfl(incl, 63, 64);
+        ccarry += __shfl(cincl, 63, 64);
     }
-    if (t == 1023) {
-        offs[total] = part[1023];
-        coffs[total] = cpart[1023];
+    if (threadIdx.x == 0) {
+        int t = 0, ct = 0;
+        for (int k = 0; k < 16; ++k) {
+            t += wsum[k];
+            ct += wcsum[k];
+        }
+        offs[total] = t;
+        coffs[total] = ct;
     }
 }
 
-// Scatter the (row, weight) pairs into their destination's list: the workgroup counts its share in LDS again,
-// reserves one contiguous range per destination with a single returning global atomic, then ranks its pairs inside
-// that range with LDS atomics.
-__global__ __launch_bounds__(TIG_T) void tig_fill_kernel(const int32_t* __restrict__ idx, const float* __restrict__ w, int N,
-                                                         int S, int per_block, int* __restrict__ cursor,
-                                                         int2* __restrict__ list, const int* __restrict__ coff) {
+// Scatter the row ids into their nearest neighbour's list: the workgroup counts its share in LDS again, reserves one
+// contiguous range per destination with a single returning global atomic, then ranks its rows inside that range with
+// LDS atomics.
+__global__ __launch_bounds__(TIG_T) void tig_fill_kernel(const int32_t* __restrict__ idx, int N, int S, int per_block,
+                                                         int* __restrict__ cursor, int* __restrict__ list,
+                                                         const int* __restrict__ coff) {
     extern __shared__ int lh[];  // [S] counts, then [S] running positions
     const int b = blockIdx.y;
     const long long row0 = coff ? coff[b] : (long long)b * N;
     if (coff) N = coff[b + 1] - coff[b];
-    if ((long long)blockIdx.x * per_block >= 3LL * N) return;   // uniform
+    if ((long long)blockIdx.x * per_block >= N) return;         // uniform
     for (int e = threadIdx.x; e < S; e += TIG_T) lh[e] = 0;
     __syncthreads();
-    const long long p0 = (long long)blockIdx.x * per_block, p1 = p0 + per_block < 3LL * N ? p0 + per_block : 3LL * N;
+    const long long p0 = (long long)blockIdx.x * per_block, p1 = p0 + per_block < N ? p0 + per_block : N;
     const int32_t* ib = idx + row0 * 3;
-    const float* wb = w + row0 * 3;
-    for (long long e = p0 + threadIdx.x; e < p1; e += TIG_T) atomicAdd(&lh[clamp_idx(ib[e], S)], 1);
+    for (long long e = p0 + threadIdx.x; e < p1; e += TIG_T) atomicAdd(&lh[clamp_idx(ib[3 * e], S)], 1);
     __syncthreads();
     for (int e = threadIdx.x; e < S; e += TIG_T) {
         const int c = lh[e];
@@ -280,40 +308,88 @@ __global__ __launch_bounds__(TIG_T) void tig_fill_kernel(const int32_t* __restri
     }
     __syncthreads();
     for (long long e = p0 + threadIdx.x; e < p1; e += TIG_T) {
-        const int pos = atomicAdd(&lh[clamp_idx(ib[e], S)], 1);
-        list[pos] = make_int2((int)(row0 + e / 3), __float_as_int(wb[e]));
+        const int pos = atomicAdd(&lh[clamp_idx(ib[3 * e], S)], 1);
+        list[pos] = (int)(row0 + e);
     }
 }
 
-// one wavefront per 64-entry chunk of a destination's list; lane l owns channels l, l + 64, ... of the row
+// one wavefront per 64-row chunk of a destination's list; lane l owns channels l and l + 64 of a 128-channel block
+constexpr int TIG_SLOTS = 32;
 __global__ __launch_bounds__(kBlock) void tig_reduce_kernel(const float* __restrict__ dout, int64_t out_stride, int64_t out_offset,
+                                                            const int32_t* __restrict__ idx, const float* __restrict__ w,
                                                             const int* __restrict__ offs, const int* __restrict__ coffs,
-                                                            const int2* __restrict__ list, int BS, int D,
+                                                            const int* __restrict__ list, int BS, int S, int D,
                                                             float* __restrict__ dpoints2) {
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)));
+    __shared__ float tab[kBlock / 64][TIG_SLOTS][128];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kBlock / 64) + wv));
     if (wave >= coffs[BS]) return;
     int lo_d = 0, hi_d = BS;  // destination with coffs[dest] <= wave < coffs[dest + 1]
     while (hi_d - lo_d > 1) {
         const int mid = (lo_d + hi_d) >> 1;
         if (coffs[mid] <= wave) lo_d = mid; else hi_d = mid;
     }
-    const int dest = lo_d;
+    const int dest = lo_d, cloud_base = (dest / S) * S;
     const int lo = offs[dest] + (wave - coffs[dest]) * TIG_CHUNK, end = offs[dest + 1];
     const int hi = lo + TIG_CHUNK < end ? lo + TIG_CHUNK : end;
     for (int c0 = 0; c0 < D; c0 += 128) {
         float a0 = 0.0f, a1 = 0.0f;
         const int ca = c0 + lane, cb = c0 + 64 + lane;
-        for (int e = lo; e < hi; ++e) {
-            const int2 it = list[e];
-            const float ww = __int_as_float(it.y);
-            const float* row = dout + (long long)it.x * out_stride + out_offset;
-            if (ca < D) a0 += __fmul_rn(row[ca], ww);
-            if (cb < D) a1 += __fmul_rn(row[cb], ww);
+        int tag = -1, nslots = 0;          // lane s < nslots: destination held by table slot s
+        constexpr int U = 4;               // rows in flight: their ids, neighbour lists and data are fetched together
+        for (int e0 = lo; e0 < hi; e0 += U) {
+            int row[U], i1[U], i2[U];
+            float w0[U], w1[U], w2[U], v0[U], v1[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) row[u] = __builtin_amdgcn_readfirstlane(list[e0 + u < hi ? e0 + u : hi - 1]);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float* src = dout + (long long)row[u] * out_stride + out_offset;
+                v0[u] = ca < D ? src[ca] : 0.0f;
+                v1[u] = cb < D ? src[cb] : 0.0f;
+                const int32_t* ir = idx + (long long)row[u] * 3;
+                const float* wr = w + (long long)row[u] * 3;
+                i1[u] = ir[1], i2[u] = ir[2];
+                w0[u] = wr[0], w1[u] = wr[1], w2[u] = wr[2];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (e0 + u >= hi) break;   // uniform
+                a0 += __fmul_rn(v0[u], w0[u]);
+                a1 += __fmul_rn(v1[u], w0[u]);
+#pragma unroll
+                for (int k = 1; k < 3; ++k) {
+                    const int d = cloud_base + clamp_idx(k == 1 ? i1[u] : i2[u], S);
+                    const float wk = k == 1 ? w1[u] : w2[u];
+                    const unsigned long long hit = __ballot(tag == d);
+                    int slot;
+                    if (hit) {
+                        slot = (int)__builtin_ctzll(hit);
+                    } else if (nslots < TIG_SLOTS) {
+                        slot = nslots++;
+                        if (lane == slot) tag = d;
+                        tab[wv][slot][lane] = 0.0f;
+                        tab[wv][slot][lane + 64] = 0.0f;
+                    } else {   // table full (scattered neighbours): this contribution goes straight to memory
+                        float* q = dpoints2 + (long long)d * D;
+                        if (ca < D) atomicAdd(q + ca, __fmul_rn(v0[u], wk));
+                        if (cb < D) atomicAdd(q + cb, __fmul_rn(v1[u], wk));
+                        continue;
+                    }
+                    tab[wv][slot][lane] += __fmul_rn(v0[u], wk);       // lane-private cells: plain read-modify-write
+                    tab[wv][slot][lane + 64] += __fmul_rn(v1[u], wk);
+                }
+            }
         }
         float* dst = dpoints2 + (long long)dest * D;
         if (ca < D) atomicAdd(dst + ca, a0);
         if (cb < D) atomicAdd(dst + cb, a1);
+        for (int sl = 0; sl < nslots; ++sl) {
+            const int d = __builtin_amdgcn_readlane(tag, sl);
+            float* q = dpoints2 + (long long)d * D;
+            if (ca < D) atomicAdd(q + ca, tab[wv][sl][lane]);
+            if (cb < D) atomicAdd(q + cb, tab[wv][sl][lane + 64]);
+        }
     }
 }
 
@@ -417,9 +493,9 @@ extern "C" int pn2_three_interpolate_f32(const float* points2, int64_t pb, int64
 // bucketing pays off once the op is large; below this many atomics the direct kernel is faster
 static bool tig_sorted(int B, int N, int S, int D) { return (long long)B * N * D >= (1LL << 22) && S <= 8192 && B <= 65535; }
 
-// hist, offs (+1), cursor, coffs: ints; list: (row, weight) pairs
+// hist, offs (+1), cursor, coffs: ints; list: row ids
 static size_t tig_workspace(int B, long long rows, int S) {
-    return (size_t)(4 * ((size_t)B * S + 4)) * sizeof(int) + 16 + (size_t)rows * 3 * sizeof(int2);
+    return (size_t)(4 * ((size_t)B * S + 4)) * sizeof(int) + 16 + (size_t)rows * sizeof(int);
 }
 
 extern "C" size_t pn2_three_interpolate_grad_workspace_bytes(int B, int N, int S, int D) {
@@ -448,29 +524,28 @@ static int tig_run(const float* dout, int64_t out_stride, int64_t out_offset, co
     int* offs = hist + BS + 4;
     int* cursor = offs + BS + 4;
     int* coffs = cursor + BS + 4;
-    int2* list = (int2*)(((uintptr_t)(coffs + BS + 4) + 15) & ~(uintptr_t)15);
-    const long long pairs = rows * 3;
+    int* list = (int*)(((uintptr_t)(coffs + BS + 4) + 15) & ~(uintptr_t)15);
     PN2_HIP_CHECK(hipMemsetAsync(hist, 0, (size_t)(BS + 4) * sizeof(int), s));
     // ~64 workgroups per launch keep the per-destination global atomics few; S ints of LDS each
     int shares = 64 / B;
     if (shares < 1) shares = 1;
-    int per_block = pn2::ceil_div(pn2::ceil_div(3LL * N, shares), TIG_T) * TIG_T;
-    shares = pn2::ceil_div(3LL * N, per_block);
+    int per_block = pn2::ceil_div(pn2::ceil_div(N, shares), TIG_T) * TIG_T;
+    shares = pn2::ceil_div(N, per_block);
     const size_t lds = (size_t)S * sizeof(int);
     {
-        pn2::prof::Scope sc_("tig_count", s, 8.0 * pairs, 0);
+        pn2::prof::Scope sc_("tig_count", s, 8.0 * rows, 0);
         hipLaunchKernelGGL(tig_count_kernel, dim3(shares, B), dim3(TIG_T), lds, s, idx, N, S, per_block, hist, coff);
     }
     PN2_LAUNCH("tig_scan", 12.0 * BS, 0, tig_scan_kernel, dim3(1), dim3(1024), s, (const int*)hist, BS, offs, cursor, coffs);
     {
-        pn2::prof::Scope sc_("tig_fill", s, 24.0 * pairs, 0);
-        hipLaunchKernelGGL(tig_fill_kernel, dim3(shares, B), dim3(TIG_T), lds, s, idx, w, N, S, per_block, cursor, list, coff);
+        pn2::prof::Scope sc_("tig_fill", s, 8.0 * rows, 0);
+        hipLaunchKernelGGL(tig_fill_kernel, dim3(shares, B), dim3(TIG_T), lds, s, idx, N, S, per_block, cursor, list, coff);
     }
-    // sum over destinations of ceil(len / 64) <= pairs / 64 + B*S: wavefronts beyond the real chunk count exit at once
-    const long long waves = pairs / TIG_CHUNK + BS + 1;
+    // sum over destinations of ceil(len / 64) <= rows / 64 + B*S: wavefronts beyond the real chunk count exit at once
+    const long long waves = rows / TIG_CHUNK + BS + 1;
     if (waves > 0x7FFFFFFFLL / 64) return PN2_E_BADARG;
     PN2_LAUNCH("three_interpolate_grad", bytes, 0, tig_reduce_kernel, dim3((unsigned)pn2::ceil_div(waves, kBlock / 64)), dim3(kBlock),
-               s, dout, out_stride, out_offset, (const int*)offs, (const int*)coffs, (const int2*)list, BS, D, dpoints2);
+               s, dout, out_stride, out_offset, idx, w, (const int*)offs, (const int*)coffs, (const int*)list, BS, S, D, dpoints2);
     PN2_LAUNCH_CHECK();
     return 0;
 }
