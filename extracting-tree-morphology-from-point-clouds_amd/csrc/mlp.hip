@@ -1264,6 +1264,7 @@ Operand act_operand(const Act& a, int rows, int cols) {
 
 // Tile choice: 128-tiles unless they would leave most of the chip idle (deep levels have a few hundred rows).
 inline int pick_tile(int M, int N, int nsplit) {
+    // (128-row tiles for narrow outputs of long matrices were measured: 20.8 -> 21.3 .. 22.5 ms per raster-mode tree)
     if (M <= 64 || N <= 64) return 64;   // a narrow output (the 128 -> 2/3 head convs) wastes less of a 64-tile
     const long long big = (long long)pn2::ceil_div(M, 128) * pn2::ceil_div(N, 128) * nsplit;
     return big >= 96 ? 128 : 64;

@@ -278,3 +278,41 @@ def test_fused_forward_hierarchical_equals_sequential(pn2):
     (l0, g0), (l1, g1) = res["sequential"], res["fused"]
     assert abs(l0 - l1) <= 1e-5 * abs(l0)
     _grads_close(g0, g1)
+
+
+def test_long_and_unsupported_streams(pn2, monkeypatch):
+    """A stream longer than one pass holds is cut into several passes with the same result as the loop (the per-pass limit,
+    PN2_MAX_SEGMENTS = 128 mini-batches, is lowered to 4 here so that an ordinary stream needs four passes); a stream the
+    fused path does not take (a padded raster shorter than the neighbourhood size) silently runs the loop."""
+    from pn2_amd import _hip, streaming
+    from pn2_amd.PointNet2.PointNet2 import PointNet2
+    mbs, labels = _tree_minibatches(40000, seed=9, mbs=10)
+    assert len(mbs) >= 9
+    monkeypatch.setattr(_hip, "MAX_SEGMENTS", 4)
+    assert len(list(streaming._passes(mbs))) >= 3
+    res = {}
+    for mode in ("sequential", "fused"):
+        os.environ["PN2_STREAMING"] = mode
+        try:
+            torch.manual_seed(3)
+            model = PointNet2(depth=5).cuda().train()
+            torch.manual_seed(4)
+            loss, _ = model.forward_hierarchical_streaming(dict(labels, mini_batches=iter(mbs)), return_loss=True, scaler=_Scaler())
+            res[mode] = (loss, {n: p.grad.detach().clone() for n, p in model.named_parameters()},
+                         {n: b.detach().clone() for n, b in model.named_buffers()})
+        finally:
+            os.environ.pop("PN2_STREAMING", None)
+    assert abs(res["fused"][0] - res["sequential"][0]) <= 1e-5 * abs(res["sequential"][0])
+    _grads_close(res["sequential"][1], res["fused"][1])
+    for n, b in res["sequential"][2].items():
+        if "num_batches" in n:
+            assert int(res["fused"][2][n]) == int(b) == len(mbs)
+        else:
+            np.testing.assert_allclose(res["fused"][2][n].cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=1e-5)
+    # a raster padded to 20 points: K = min(32, 20) differs from the other mini-batches -> not a fused stream
+    tiny = {"coords": torch.randn(2, 3, 20).cuda(), "feats": torch.ones(2, 4, 20).cuda(), "masks_pad": torch.ones(2, 20, dtype=torch.bool).cuda(),
+            "masks_off": torch.ones(40, dtype=torch.bool).cuda(), "point_ids": torch.arange(40).cuda()}
+    assert not streaming.supported([tiny], model)
+    with torch.no_grad():
+        out = model.forward_hierarchical_streaming({"cloud_length": 40, "mini_batches": [tiny]}, return_loss=False)
+    assert tuple(out["offset_predictions"].shape) == (40, 3) and torch.isfinite(out["offset_predictions"]).all()
