@@ -32,5 +32,6 @@ python3 $R/tools/pmc_traffic.py $(find /tmp/pmc_fetch -name "*counter_collection
 echo "pmc done"
 cd $R
 timeout -k 10 600 python tools/bench_features.py > $O/bench_features.json 2>> $O/bench.err
+timeout -k 10 300 python tools/bench_datapath.py > $O/bench_datapath.json 2>> $O/bench.err
 echo "secondary benches done"
 ls -la $O
