@@ -943,6 +943,513 @@ __global__ __launch_bounds__(kXT) void fps_multi_kernel(const float* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Spatially ordered multi-pick rounds: the same exchange as fps_multi_kernel, but the update is skipped where it
+// provably changes nothing.
+//
+// A new centroid c lowers d[p] only where |p - c|^2 < d[p].  If every point a wavefront holds lies in a box whose
+// distance to c is at least the wavefront's largest d, nothing it holds changes: its lanes' best-two, its published
+// candidate and its bound all stay what they were, and the wavefront goes straight to the barrier.  For that to be the
+// common case a wavefront has to hold NEIGHBOURS, so the cloud is put into Morton order first (64^3 cells of the cloud's
+// bounding cube; fps_box_kernel, fps_order_kernel and one radix sort of (cell << 20 | index) keys, ~60 us) and wavefront
+// w takes the w-th run of 64 * ppt sorted positions.  On the 262144-point tree a centroid touches ~12 of the 256
+// wavefronts after the first few dozen samples (tools/sim/fps_rounds.py), so a round is the serial exchange plus the
+// update and selection of ONE busy wavefront instead of two wavefronts per SIMD updating 16 points per lane each.
+// The order only decides who holds which point: keys carry the ORIGINAL index, lanes compare full (d, ~index) keys
+// (slots are no longer in index order), so samples and tie-breaks are bit-identical to the unsorted kernels.
+// The box test is made safe against the rounding of both sides: the update computes fl((dx*dx + dy*dy) + dz*dz) with
+// relative error < 2^-21.4 of the exact value and so does the box distance, hence the skip requires
+// box_distance * (1 - 2^-19) >= max d; non-finite values fail the comparison and are treated as "touched".
+constexpr int kCellBits = 4;                    // per axis: 16 x 16 x 16 cells of the cloud's bounding box
+constexpr int kCells = 1 << (3 * kCellBits);
+
+__device__ __forceinline__ unsigned ord_enc(float f) {   // order-preserving float -> u32
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord_dec(unsigned e) { return __uint_as_float((e & 0x80000000u) ? (e & 0x7FFFFFFFu) : ~e); }
+
+// The ordering kernels: workgroups of kOT threads, kOP points per thread (loads of a thread are independent: all in flight).
+constexpr int kOT = 1024, kOP = 8;
+
+// box[b] = {max enc(x), max enc(y), max enc(z), max ~enc(x), max ~enc(y), max ~enc(z)} (zeroed by the workspace memset);
+// one atomic per workgroup and value (same-address atomics retire one at a time)
+__global__ __launch_bounds__(kOT) void fps_box_kernel(const float* __restrict__ xyz, int64_t sb, int64_t sn, int64_t sc, int N,
+                                                      unsigned* __restrict__ box) {
+    __shared__ unsigned red[kOT / 64][6];
+    const int b = blockIdx.y, t = threadIdx.x;
+    const float* p = xyz + (int64_t)b * sb;
+    unsigned v[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < kOP; ++k) {
+        const int n = (blockIdx.x * kOP + k) * kOT + t;
+        if (n < N) {
+            const float* q = p + (int64_t)n * sn;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const unsigned e = ord_enc(q[a * sc]);
+                v[a] = max(v[a], e);
+                v[3 + a] = max(v[3 + a], ~e);
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        const unsigned w = pn2::wave_max_u32(v[a]);
+        if ((t & 63) == 0) red[t >> 6][a] = w;
+    }
+    __syncthreads();
+    if (t < 6) {
+        unsigned w = 0;
+#pragma unroll
+        for (int k = 0; k < kOT / 64; ++k) w = max(w, red[k][t]);
+        atomicMax(box + b * 8 + t, w);
+    }
+}
+
+__device__ __forceinline__ unsigned spread3(unsigned v) {   // bit i -> bit 3 i (good for 8 bits)
+    v = (v | (v << 8)) & 0x0000F00Fu;
+    v = (v | (v << 4)) & 0x000C30C3u;
+    v = (v | (v << 2)) & 0x00249249u;
+    return v;
+}
+
+// Morton number of the cell of a point: every axis of the cloud's box is cut into 16 (non-finite values land in cell 0 / 15).
+struct CellGrid {
+    float lo[3], scale[3];
+};
+__device__ __forceinline__ CellGrid cell_grid(const unsigned* box) {
+    CellGrid c;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        c.lo[a] = ord_dec(~box[3 + a]);
+        const float ext = ord_dec(box[a]) - c.lo[a];
+        c.scale[a] = ext > 0.0f ? (float)(1 << kCellBits) / ext : 0.0f;
+    }
+    return c;
+}
+__device__ __forceinline__ unsigned cell_of(const CellGrid& c, float x, float y, float z) {
+    const float top = (float)((1 << kCellBits) - 1);
+    const unsigned cx = (unsigned)fminf(fmaxf((x - c.lo[0]) * c.scale[0], 0.0f), top);
+    const unsigned cy = (unsigned)fminf(fmaxf((y - c.lo[1]) * c.scale[1], 0.0f), top);
+    const unsigned cz = (unsigned)fminf(fmaxf((z - c.lo[2]) * c.scale[2], 0.0f), top);
+    return spread3(cx) | (spread3(cy) << 1) | (spread3(cz) << 2);
+}
+
+// total[b][cell] = points of cloud b in the cell (LDS histogram per workgroup, one global add per non-empty cell)
+__global__ __launch_bounds__(kOT) void fps_hist_kernel(const float* __restrict__ xyz, int64_t sb, int64_t sn, int64_t sc, int N,
+                                                       const unsigned* __restrict__ box, unsigned* __restrict__ total) {
+    __shared__ unsigned h[kCells];
+    const int b = blockIdx.y, t = threadIdx.x;
+    for (int c = t; c < kCells; c += kOT) h[c] = 0;
+    __syncthreads();
+    const CellGrid cg = cell_grid(box + b * 8);
+    const float* p = xyz + (int64_t)b * sb;
+#pragma unroll
+    for (int k = 0; k < kOP; ++k) {
+        const int n = (blockIdx.x * kOP + k) * kOT + t;
+        if (n < N) {
+            const float* q = p + (int64_t)n * sn;
+            atomicAdd(&h[cell_of(cg, q[0], q[sc], q[2 * sc])], 1u);
+        }
+    }
+    __syncthreads();
+    for (int c = t; c < kCells; c += kOT)
+        if (h[c]) atomicAdd(total + (size_t)b * kCells + c, h[c]);
+}
+
+// order[b][first position of the cell + arrival number] = n.  A workgroup counts its points per cell in LDS (every point
+// keeps its arrival number), reserves a run per non-empty cell with ONE global atomic, then places its points.  The order
+// INSIDE a cell is whatever order the atomics retire in -- it only decides which lane of which wavefront keeps the point,
+// never a result.
+__global__ __launch_bounds__(kOT) void fps_scatter_kernel(const float* __restrict__ xyz, int64_t sb, int64_t sn, int64_t sc, int N,
+                                                          const unsigned* __restrict__ box, const unsigned* __restrict__ total,
+                                                          unsigned* __restrict__ cursor, unsigned* __restrict__ order) {
+    __shared__ unsigned base[kCells];   // first position of the cell; after the reservation: first position of this workgroup's run
+    __shared__ unsigned h[kCells];
+    __shared__ unsigned part[kOT];
+    const int b = blockIdx.y, t = threadIdx.x;
+    constexpr int PER = kCells / kOT;
+    unsigned v[PER], sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        v[k] = total[(size_t)b * kCells + t * PER + k];
+        sum += v[k];
+        h[t * PER + k] = 0;
+    }
+    part[t] = sum;
+    __syncthreads();
+    for (int s = 1; s < kOT; s <<= 1) {   // inclusive scan of the partial sums
+        const unsigned add = t >= s ? part[t - s] : 0u;
+        __syncthreads();
+        part[t] += add;
+        __syncthreads();
+    }
+    unsigned run = part[t] - sum;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        base[t * PER + k] = run;
+        run += v[k];
+    }
+    const CellGrid cg = cell_grid(box + b * 8);
+    const float* p = xyz + (int64_t)b * sb;
+    unsigned cell[kOP], arrival[kOP];
+#pragma unroll
+    for (int k = 0; k < kOP; ++k) {
+        const int n = (blockIdx.x * kOP + k) * kOT + t;
+        cell[k] = 0, arrival[k] = 0;
+        if (n < N) {
+            const float* q = p + (int64_t)n * sn;
+            cell[k] = cell_of(cg, q[0], q[sc], q[2 * sc]);
+            arrival[k] = atomicAdd(&h[cell[k]], 1u);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int c = t * PER + k;
+        if (h[c]) base[c] += atomicAdd(cursor + (size_t)b * kCells + c, h[c]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kOP; ++k) {
+        const int n = (blockIdx.x * kOP + k) * kOT + t;
+        if (n < N) order[(size_t)b * N + base[cell[k]] + arrival[k]] = (unsigned)n;
+    }
+}
+
+// Round of the ordered kernel (G <= 64 members, NW wavefronts each):
+//   every wavefront   box tests; if touched: update, lane best + runner-up (max / min trees over the slots, no serial
+//                     compare chain), wavefront candidate + bound into LDS                               -> barrier 1
+//   wavefront 0       workgroup candidate + bound, five granules published; polls all members' granules (lane l = member
+//                     l); ranks ALL candidates at once (keys through LDS, each lane counts the keys that beat "its" key
+//                     among half of the members) instead of KM dependent arg-max reductions; the candidates of rank
+//                     0 .. KM go to the list, the acceptance chain runs on it                               -> barrier 2
+// Bounds travel as float bits only (low word taken as all ones): a bound may be loose, never low -- a loose one can
+// only shorten the accepted prefix, which the next round makes up for.
+template <int PPT, int KM>
+__global__ __launch_bounds__(kXT) void fps_sorted_kernel(const float* __restrict__ xyz, int64_t sb, int64_t sn, int64_t sc,
+                                                         int B, int N, int npoint, const int64_t* __restrict__ start,
+                                                         const unsigned* __restrict__ order, int32_t* __restrict__ out_idx,
+                                                         float* __restrict__ out_xyz, u64* gran, XcdHeader* hdr, int G,
+                                                         Knobs kn) {
+    constexpr int T = kXT, NW = T / 64;
+    constexpr int kGran = 5;  // granules per member and round: {key, x, y, z} of its best point + the bound
+    static_assert(PPT <= 16, "slot numbers travel in four bits");
+    __shared__ u64 s_wkey[NW];        // a wavefront's candidate and bound: rewritten only in rounds that touch it
+    __shared__ unsigned s_wbound[NW];
+    __shared__ float s_wxyz[NW][3];
+    __shared__ u64 s_key[64];         // the members' candidates of this round, for the ranking
+    __shared__ unsigned s_cnt[64];
+    __shared__ float s_cent[2][KM][3];
+    __shared__ u64 s_ckey[2][KM + 1];
+    __shared__ int s_m[2];
+    __shared__ int s_role[4];
+    __shared__ float s_px[PPT * kXT], s_py[PPT * kXT], s_pz[PPT * kXT];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int b = blockIdx.x; b < B; b += gridDim.x) poison_rows(out_idx, out_xyz, (size_t)b * npoint, npoint, tid, T);
+    __syncthreads();   // every store of the fill has left before thread 0's release + arrival in xcd_roles
+    if (tid == 0) xcd_roles(hdr, G, s_role, kn);
+    __syncthreads();
+    const int group = s_role[0], g = s_role[1], ngroups = s_role[2];
+    const bool local = s_role[3] != 0;
+    if (group < 0 || ngroups <= 0) return;
+
+    const int ppt = (N + G * T - 1) / (G * T);
+    const int first = (g * NW + wave) * (ppt * 64) + lane;   // sorted position of slot 0; slot j is 64 * j further on
+    for (int b = group; b < B; b += ngroups) {
+        const float* p = xyz + (int64_t)b * sb;
+        const unsigned* ord = order + (size_t)b * N;
+        f2 x[PPT / 2], y[PPT / 2], z[PPT / 2], d[PPT / 2];
+        unsigned pk[PPT];   // original index << 4 | slot
+        unsigned ehi[3] = {0, 0, 0}, elo[3] = {0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const int pos = first + j * 64;
+            const bool ok = j < ppt && pos < N;
+            const int n = ok ? (int)ord[pos] : 0;
+            const float* q = p + (int64_t)n * sn;
+            const float qx = q[0], qy = q[sc], qz = q[2 * sc];
+            pk[j] = ((unsigned)n << 4) | (unsigned)j;
+            x[j >> 1][j & 1] = qx;
+            y[j >> 1][j & 1] = qy;
+            z[j >> 1][j & 1] = qz;
+            d[j >> 1][j & 1] = ok ? 1e10f : -1.0f;
+            s_px[j * T + tid] = qx;
+            s_py[j * T + tid] = qy;
+            s_pz[j * T + tid] = qz;
+            if (ok) {
+                const unsigned e0 = ord_enc(qx), e1 = ord_enc(qy), e2 = ord_enc(qz);
+                ehi[0] = max(ehi[0], e0), ehi[1] = max(ehi[1], e1), ehi[2] = max(ehi[2], e2);
+                elo[0] = max(elo[0], ~e0), elo[1] = max(elo[1], ~e1), elo[2] = max(elo[2], ~e2);
+            }
+        }
+        // the wavefront's box (wave-uniform)
+        float blo[3], bhi[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            bhi[a] = ord_dec(pn2::wave_max_u32(ehi[a]));
+            blo[a] = ord_dec(~pn2::wave_max_u32(elo[a]));
+        }
+        float wmax = 1e10f;   // the wavefront's largest d (high word of its candidate key)
+        int m = 1;            // centroids to apply this round
+        float ccx[KM], ccy[KM], ccz[KM];
+        {
+            const int far = (int)start[b];
+            const float* c = p + (int64_t)far * sn;
+            ccx[0] = c[0], ccy[0] = c[sc], ccz[0] = c[2 * sc];
+#pragma unroll
+            for (int t = 1; t < KM; ++t) ccx[t] = ccx[0], ccy[t] = ccy[0], ccz[t] = ccz[0];
+            if (g == 0 && tid == 0) {
+                out_idx[(size_t)b * npoint] = far;
+                if (out_xyz) {
+                    float* o = out_xyz + (size_t)b * npoint * 3;
+                    o[0] = ccx[0], o[1] = ccy[0], o[2] = ccz[0];
+                }
+            }
+        }
+        int count = 1;
+        u64* gb = gran + (size_t)b * npoint * kGran * G;
+#ifdef PN2_FPS_DIAG
+        unsigned long long st[6] = {0, 0, 0, 0, 0, 0}, tprev = 0, nrounds = 0, ntouch = 0, tupd = 0, tsel = 0;
+        const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime(), ct0 = __builtin_amdgcn_s_memtime();
+#endif
+
+        for (int round = 0; count < npoint; ++round) {
+            const int buf = round & 1;
+#ifdef PN2_FPS_DIAG
+            tprev = __builtin_amdgcn_s_memtime();
+            ++nrounds;
+#endif
+            // ---- update with those of the m accepted centroids that can reach this wavefront's box
+            bool touched = false;
+#pragma unroll
+            for (int t = 0; t < KM; ++t) {
+                if (t < m) {
+                    const float bx = fmaxf(fmaxf(blo[0] - ccx[t], ccx[t] - bhi[0]), 0.0f);
+                    const float by = fmaxf(fmaxf(blo[1] - ccy[t], ccy[t] - bhi[1]), 0.0f);
+                    const float bz = fmaxf(fmaxf(blo[2] - ccz[t], ccz[t] - bhi[2]), 0.0f);
+                    const float bd = (bx * bx + by * by) + bz * bz;
+                    const bool far_away = bd * (1.0f - 1.0f / 524288.0f) >= wmax;   // false for NaN: treated as touched
+                    if (!far_away) {   // wave-uniform
+                        touched = true;
+                        const f2 c2x = {ccx[t], ccx[t]}, c2y = {ccy[t], ccy[t]}, c2z = {ccz[t], ccz[t]};
+#pragma unroll
+                        for (int q = 0; q < PPT / 2; ++q) {
+                            const f2 dx = x[q] - c2x, dy = y[q] - c2y, dz = z[q] - c2z;
+                            const f2 dist = (dx * dx + dy * dy) + dz * dz;
+                            d[q][0] = fminf(d[q][0], dist[0]);   // slots beyond N hold -1 and stay -1
+                            d[q][1] = fminf(d[q][1], dist[1]);
+                        }
+                    }
+                }
+            }
+#ifdef PN2_FPS_DIAG
+            const unsigned long long tu0 = __builtin_amdgcn_s_memtime();
+            if (touched) tupd += tu0 - tprev;
+#endif
+            STAMP(0);  // box tests + update
+            if (touched) {
+#ifdef PN2_FPS_DIAG
+                ++ntouch;
+#endif
+                // ---- this lane's best (exact key: slots are in Morton order, ties go to the lowest ORIGINAL index) and the
+                // largest d among its other slots, as max / min trees
+                float mx[PPT];
+#pragma unroll
+                for (int j = 0; j < PPT; ++j) mx[j] = d[j >> 1][j & 1];
+#pragma unroll
+                for (int w = 1; w < PPT; w <<= 1)
+#pragma unroll
+                    for (int j = 0; j + w < PPT; j += 2 * w) mx[j] = fmaxf(mx[j], mx[j + w]);
+                const float m1 = mx[0];
+                unsigned mn[PPT];
+#pragma unroll
+                for (int j = 0; j < PPT; ++j) mn[j] = d[j >> 1][j & 1] == m1 ? pk[j] : 0xFFFFFFFFu;
+#pragma unroll
+                for (int w = 1; w < PPT; w <<= 1)
+#pragma unroll
+                    for (int j = 0; j + w < PPT; j += 2 * w) mn[j] = min(mn[j], mn[j + w]);
+                const unsigned c1 = mn[0];
+#pragma unroll
+                for (int j = 0; j < PPT; ++j) mx[j] = pk[j] == c1 ? -1.0f : d[j >> 1][j & 1];
+#pragma unroll
+                for (int w = 1; w < PPT; w <<= 1)
+#pragma unroll
+                    for (int j = 0; j + w < PPT; j += 2 * w) mx[j] = fmaxf(mx[j], mx[j + w]);
+                const float m2 = mx[0];
+                const int j1 = (int)(c1 & 15u);
+                const u64 k1 = m1 < 0.0f ? 0ull : (((u64)__float_as_uint(m1)) << 32) | (u64)(0xFFFFFFFFu - (c1 >> 4));
+                const unsigned b2 = m2 < 0.0f ? 0u : __float_as_uint(m2);
+                // ---- wavefront: best point (key + coordinates) and the float bits of the largest other d
+                int owner;
+                const u64 w1 = wave_max_key_owner(k1, owner);
+                const unsigned wb = pn2::wave_max_u32(lane == owner ? b2 : (unsigned)(k1 >> 32));
+                wmax = __uint_as_float((unsigned)(w1 >> 32));
+                if (lane == owner) {
+                    s_wkey[wave] = w1;
+                    s_wbound[wave] = wb;
+                    s_wxyz[wave][0] = s_px[j1 * T + tid];
+                    s_wxyz[wave][1] = s_py[j1 * T + tid];
+                    s_wxyz[wave][2] = s_pz[j1 * T + tid];
+                }
+            }
+#ifdef PN2_FPS_DIAG
+            if (touched) tsel += __builtin_amdgcn_s_memtime() - tu0;
+#endif
+            STAMP(1);  // lane best + runner-up, wavefront candidate
+            lds_barrier();
+            STAMP(2);  // barrier 1
+            if (wave == 0) {
+                u64* slot = gb + (size_t)round * kGran * G;
+                const unsigned tag = (unsigned)(round + 1);
+                // ---- workgroup: its best point + the bound on everything else it holds (the other wavefronts' winners and
+                // every wavefront's bound); the lane that holds the best winner publishes all five granules
+                const u64 mine = lane < NW ? s_wkey[lane] : 0ull;
+                const unsigned mb = lane < NW ? s_wbound[lane] : 0u;
+                int o1;
+                const u64 best = wave_max_key_owner(mine, o1);
+                const unsigned others = lane == o1 ? mb : max(mb, (unsigned)(mine >> 32));
+                const unsigned bound = pn2::wave_max_u32(others);
+                if (lane == o1) {
+                    u64* dst = slot + g;
+                    const u64 v0 = best | kValid;
+                    const u64 v1 = (((u64)tag) << 32) | (u64)__float_as_uint(s_wxyz[lane < NW ? lane : 0][0]);
+                    const u64 v2 = (((u64)tag) << 32) | (u64)__float_as_uint(s_wxyz[lane < NW ? lane : 0][1]);
+                    const u64 v3 = (((u64)tag) << 32) | (u64)__float_as_uint(s_wxyz[lane < NW ? lane : 0][2]);
+                    const u64 v4 = (((u64)bound) << 32) | 0xFFFFFFFFull | kValid;
+                    if (local) {
+                        __hip_atomic_store(dst, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_store(dst + G, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_store(dst + 2 * G, v2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_store(dst + 3 * G, v3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_store(dst + 4 * G, v4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    } else {
+                        st_granule(dst, v0);
+                        st_granule(dst + G, v1);
+                        st_granule(dst + 2 * G, v2);
+                        st_granule(dst + 3 * G, v3);
+                        st_granule(dst + 4 * G, v4);
+                    }
+                }
+                STAMP(3);  // workgroup candidate + publish
+                // ---- poll: lane l reads the five granules of member l
+                u64 ek = 0;
+                unsigned hb = 0, ex = 0, ey = 0, ez = 0;
+                bool dead = false;
+                {
+                    const u64* src0 = slot + (lane < G ? lane : 0);
+                    unsigned spins = 0;
+                    for (;;) {
+                        const u64 v0 = ld_granule(src0), v1 = ld_granule(src0 + G), v2 = ld_granule(src0 + 2 * G),
+                                  v3 = ld_granule(src0 + 3 * G), v4 = ld_granule(src0 + 4 * G);
+                        const bool ok = ((v0 & kValid) != 0) & ((unsigned)(v1 >> 32) == tag) & ((unsigned)(v2 >> 32) == tag) &
+                                        ((unsigned)(v3 >> 32) == tag) & ((v4 & kValid) != 0);
+                        ek = lane < G ? (v0 & ~kValid) : 0ull;
+                        hb = lane < G ? (unsigned)((v4 & ~kValid) >> 32) : 0u;
+                        ex = (unsigned)v1, ey = (unsigned)v2, ez = (unsigned)v3;
+                        if (__all(ok)) break;
+                        if (!spin_alive(spins, kn, &hdr->err, kStatusHandoff)) {  // wave-uniform
+                            dead = true;   // reported to the whole workgroup through s_m below
+                            break;
+                        }
+                    }
+                }
+                STAMP(4);  // poll
+                // ---- ranks of all candidates at once: the keys go through LDS, lane l counts how many of HALF of them beat
+                // key (l & 31) [G <= 32; every lane against all of them otherwise], the halves are added through LDS again
+                s_key[lane] = ek;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                const bool split = G <= 32;   // scalar
+                const int ci = split ? (lane & 31) : lane, j0 = split ? (lane >> 5) * 16 : 0;
+                const u64 ckey = s_key[ci];
+                unsigned cnt = 0;
+                if (split) {
+#pragma unroll
+                    for (int jj = 0; jj < 16; ++jj) cnt += s_key[j0 + jj] > ckey ? 1u : 0u;
+                } else {
+#pragma unroll 16
+                    for (int jj = 0; jj < 64; ++jj) cnt += s_key[jj] > ckey ? 1u : 0u;
+                }
+                const unsigned hbmax = pn2::wave_max_u32(hb);
+                s_cnt[lane] = cnt;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                const unsigned rank = lane < G ? s_cnt[lane] + (split ? s_cnt[(lane & 31) + 32] : 0u) : 0xFFFFu;
+                const int nz = __popcll(__ballot(ek != 0ull));   // candidates there are (ranks 0 .. nz-1 exist exactly once)
+                if (rank <= (unsigned)KM && ek != 0ull) {
+                    s_ckey[buf][rank] = ek;
+                    if (rank < (unsigned)KM) {
+                        s_cent[buf][rank][0] = __uint_as_float(ex);
+                        s_cent[buf][rank][1] = __uint_as_float(ey);
+                        s_cent[buf][rank][2] = __uint_as_float(ez);
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                // ---- accepted prefix: above H (certified next-largest) and untouched by the ones accepted before it
+                u64 tk[KM];
+                float tx[KM], ty[KM], tz[KM];
+#pragma unroll
+                for (int t = 0; t < KM; ++t) {
+                    tk[t] = t < nz ? s_ckey[buf][t] : 0ull;
+                    tx[t] = s_cent[buf][t][0], ty[t] = s_cent[buf][t][1], tz[t] = s_cent[buf][t][2];
+                }
+                u64 H = (((u64)hbmax) << 32) | 0xFFFFFFFFull;
+                if (KM < nz) {
+                    const u64 next = s_ckey[buf][KM];
+                    H = next > H ? next : H;
+                }
+                int acc = 1;
+#pragma unroll
+                for (int t = 1; t < KM; ++t) {
+                    bool keep = acc == t && tk[t] != 0 && tk[t] > H;
+                    const float dt = __uint_as_float((unsigned)(tk[t] >> 32));
+#pragma unroll
+                    for (int a = 0; a < t; ++a) {
+                        const float dx = __fsub_rn(tx[t], tx[a]), dy = __fsub_rn(ty[t], ty[a]), dz = __fsub_rn(tz[t], tz[a]);
+                        keep = keep && !(pn2::norm2(dx, dy, dz) < dt);
+                    }
+                    if (keep) acc = t + 1;
+                }
+                if (acc > npoint - count) acc = npoint - count;
+                if (g == 0 && rank < (unsigned)acc && ek != 0ull && !dead) {
+                    const size_t o = (size_t)b * npoint + count + rank;
+                    out_idx[o] = (int)(0xFFFFFFFFu - (unsigned)(ek & 0xFFFFFFFFull));
+                    if (out_xyz)
+                        out_xyz[o * 3] = __uint_as_float(ex), out_xyz[o * 3 + 1] = __uint_as_float(ey),
+                                    out_xyz[o * 3 + 2] = __uint_as_float(ez);
+                }
+                if (lane == 0) s_m[buf] = dead ? -1 : acc;   // -1: the launch is dead, everybody leaves after the barrier
+            }
+            STAMP(5);  // ranks + list + chain (wave 0) / wait (others)
+            lds_barrier();
+            m = s_m[buf];
+            if (m < 0) return;    // dead launch (uniform: every thread reads the same word after the same barrier)
+#pragma unroll
+            for (int t = 0; t < KM; ++t) ccx[t] = s_cent[buf][t][0], ccy[t] = s_cent[buf][t][1], ccz[t] = s_cent[buf][t][2];
+            count += m;
+        }
+#ifdef PN2_FPS_DIAG
+        if (tid == 0 && g == 0 && b == 0) {
+            unsigned long long* dbg = (unsigned long long*)((char*)hdr + 64);   // first granule bytes (diag only)
+            for (int k = 0; k < 6; ++k) dbg[k] = st[k];
+            dbg[6] = __builtin_amdgcn_s_memtime() - ct0;
+            dbg[7] = __builtin_amdgcn_s_memrealtime() - rt0;
+            dbg[8] = (unsigned long long)local;
+            dbg[9] = nrounds;
+            dbg[10] = ntouch;
+            dbg[11] = tupd;
+            dbg[12] = tsel;
+        }
+#endif
+        __syncthreads();
+    }
+}
+
 inline bool use_xcd_kernel(int N) {
     if (getenv("PN2_FPS_NO_XCD")) return false;
     return N > kXT * kXPPT && N <= 64 * kXT * kXPPT;
@@ -1025,11 +1532,42 @@ Knobs knobs(int32_t* status) {
 
 }  // namespace
 
+// Workspace of the spatially ordered path behind the header and the granules: [boxes][cell totals][cell cursors][order].
+struct OrderLayout {
+    size_t box, total, cursor, order, end;
+};
+inline OrderLayout order_layout(size_t head, int B, int N) {
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    OrderLayout L;
+    L.box = up(head);
+    L.total = up(L.box + (size_t)B * 8 * sizeof(unsigned));
+    L.cursor = L.total + (size_t)B * kCells * sizeof(unsigned);
+    L.order = up(L.cursor + (size_t)B * kCells * sizeof(unsigned));
+    L.end = L.order + (size_t)B * N * sizeof(unsigned);
+    return L;
+}
+inline bool use_sorted(int B, int N) {
+    return getenv("PN2_FPS_NO_SORT") == nullptr && N < (1 << 27) && B <= 4096 && multi_group_size(N) <= 64;
+}
+inline int sorted_km() {
+    if (const char* e = getenv("PN2_FPS_KM")) {
+        const int v = atoi(e);
+        if (v == 4 || v == 8) return v;
+    }
+    return 4;
+}
+
+// header + granules of the XCD kernels
+inline size_t xcd_plain_bytes(int B, int N, int npoint) {
+    if (use_multi_pick(N, npoint)) return sizeof(XcdHeader) + (size_t)B * npoint * 5 * multi_group_size(N) * sizeof(u64);
+    return sizeof(XcdHeader) + (size_t)B * npoint * 4 * xcd_group_size(N) * (xcd_perwave(N) ? kXT / 64 : 1) * sizeof(u64);
+}
+
 extern "C" size_t pn2_fps_workspace_bytes(int B, int N, int npoint) {
     if (B <= 0 || N <= 0 || npoint <= 0) return 0;
     if (use_xcd_kernel(N)) {
-        if (use_multi_pick(N, npoint)) return sizeof(XcdHeader) + (size_t)B * npoint * 5 * multi_group_size(N) * sizeof(u64);
-        return sizeof(XcdHeader) + (size_t)B * npoint * 4 * xcd_group_size(N) * (xcd_perwave(N) ? kXT / 64 : 1) * sizeof(u64);
+        if (use_multi_pick(N, npoint)) return order_layout(xcd_plain_bytes(B, N, npoint), B, N).end;
+        return xcd_plain_bytes(B, N, npoint);
     }
     const Config c = pick(B, N);
     if (c.G == 0) return 0;
@@ -1046,9 +1584,41 @@ extern "C" int pn2_fps_f32(const float* xyz, int64_t sb, int64_t sn, int64_t sc,
         const size_t need = pn2_fps_workspace_bytes(B, N, npoint);
         if (workspace_bytes < need) return PN2_E_WORKSPACE;
         hipStream_t s = (hipStream_t)stream;
-        PN2_HIP_CHECK(hipMemsetAsync(workspace, 0, need, s));
         XcdHeader* hdr = (XcdHeader*)workspace;
         u64* gran = (u64*)((char*)workspace + sizeof(XcdHeader));
+        if (use_multi_pick(N, npoint) && use_sorted(B, N)) {
+            const int ppt = multi_ppt(N), G = multi_group_size(N);
+            const OrderLayout L = order_layout(xcd_plain_bytes(B, N, npoint), B, N);
+            char* w = (char*)workspace;
+            PN2_HIP_CHECK(hipMemsetAsync(workspace, 0, L.order, s));   // header, granules, boxes, cell counters
+            unsigned* box = (unsigned*)(w + L.box);
+            unsigned* total = (unsigned*)(w + L.total);
+            unsigned* cursor = (unsigned*)(w + L.cursor);
+            unsigned* order = (unsigned*)(w + L.order);
+            {
+                pn2::prof::Scope sc_("fps_order", s, (double)B * N * (3 * 12.0 + 4.0), 0.0);
+                const dim3 grid(pn2::ceil_div(N, kOT * kOP), B);
+                hipLaunchKernelGGL(fps_box_kernel, grid, dim3(kOT), 0, s, xyz, sb, sn, sc, N, box);
+                hipLaunchKernelGGL(fps_hist_kernel, grid, dim3(kOT), 0, s, xyz, sb, sn, sc, N, box, total);
+                hipLaunchKernelGGL(fps_scatter_kernel, grid, dim3(kOT), 0, s, xyz, sb, sn, sc, N, box, total, cursor, order);
+            }
+            const double fb = (double)B * (12.0 * N + 8.0 * npoint);
+            const int km = sorted_km();
+#define PN2_FPS_SORTED(P, K)                                                                                                     \
+    if (ppt == P && km == K)                                                                                                      \
+        PN2_LAUNCH("fps", fb, 0, (fps_sorted_kernel<P, K>), dim3(kXGrid), dim3(kXT), s, xyz, sb, sn, sc, B, N, npoint, start,      \
+                   (const unsigned*)order, out_idx, out_xyz, gran, hdr, G, kn);
+            PN2_FPS_SORTED(4, 4)
+            PN2_FPS_SORTED(8, 4)
+            PN2_FPS_SORTED(16, 4)
+            PN2_FPS_SORTED(4, 8)
+            PN2_FPS_SORTED(8, 8)
+            PN2_FPS_SORTED(16, 8)
+#undef PN2_FPS_SORTED
+            PN2_LAUNCH_CHECK();
+            return 0;
+        }
+        PN2_HIP_CHECK(hipMemsetAsync(workspace, 0, xcd_plain_bytes(B, N, npoint), s));   // header + granules
         if (use_multi_pick(N, npoint)) {
             const int ppt = multi_ppt(N), G = multi_group_size(N);
             const double fb = (double)B * (12.0 * N + 8.0 * npoint);
