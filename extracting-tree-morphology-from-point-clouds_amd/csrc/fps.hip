@@ -1127,6 +1127,34 @@ __global__ __launch_bounds__(kOT) void fps_scatter_kernel(const float* __restric
 //                     0 .. KM go to the list, the acceptance chain runs on it                               -> barrier 2
 // Bounds travel as float bits only (low word taken as all ones): a bound may be loose, never low -- a loose one can
 // only shorten the accepted prefix, which the next round makes up for.
+// Max over lanes 0..7 (three row shifts instead of the six steps of a full wavefront reduction), result in every lane.
+__device__ __forceinline__ unsigned max8_u32(unsigned v) {
+    v = max(v, pn2::dpp_u32<0x111, 0xF>(0u, v));
+    v = max(v, pn2::dpp_u32<0x112, 0xF>(0u, v));
+    v = max(v, pn2::dpp_u32<0x114, 0xF>(0u, v));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 7);
+}
+__device__ __forceinline__ u64 max8_key_owner(u64 k, int& owner) {
+    const unsigned hi = (unsigned)(k >> 32), lo = (unsigned)k;
+    const unsigned mh = max8_u32(hi);
+    u64 who = __ballot(hi == mh) & 0xFFull;
+    unsigned ml;
+    if (__popcll(who) == 1) {
+        owner = (int)__builtin_ctzll(who);
+        ml = (unsigned)__builtin_amdgcn_readlane((int)lo, owner);
+    } else {
+        ml = max8_u32(hi == mh ? lo : 0u);
+        who = __ballot(hi == mh && lo == ml) & 0xFFull;
+        owner = (int)__builtin_ctzll(who);
+    }
+    return ((u64)mh << 32) | ml;
+}
+
+struct alignas(16) ListEntry {
+    u64 key;
+    float x, y, z, pad;
+};
+
 template <int PPT, int KM>
 __global__ __launch_bounds__(kXT) void fps_sorted_kernel(const float* __restrict__ xyz, int64_t sb, int64_t sn, int64_t sc,
                                                          int B, int N, int npoint, const int64_t* __restrict__ start,
@@ -1140,9 +1168,7 @@ __global__ __launch_bounds__(kXT) void fps_sorted_kernel(const float* __restrict
     __shared__ unsigned s_wbound[NW];
     __shared__ float s_wxyz[NW][3];
     __shared__ u64 s_key[64];         // the members' candidates of this round, for the ranking
-    __shared__ unsigned s_cnt[64];
-    __shared__ float s_cent[2][KM][3];
-    __shared__ u64 s_ckey[2][KM + 1];
+    __shared__ ListEntry s_list[2][KM + 1];   // the round's candidates in rank order (+ the first one outside the list)
     __shared__ int s_m[2];
     __shared__ int s_role[4];
     __shared__ float s_px[PPT * kXT], s_py[PPT * kXT], s_pz[PPT * kXT];
@@ -1157,6 +1183,12 @@ __global__ __launch_bounds__(kXT) void fps_sorted_kernel(const float* __restrict
     const bool local = s_role[3] != 0;
     if (group < 0 || ngroups <= 0) return;
 
+    static_assert(KM * (KM - 1) / 2 <= 64, "one lane per candidate pair");
+    int pair_t = 1, pair_a = 0;   // this lane's pair (t, a), a < t: lane = t (t - 1) / 2 + a
+#pragma unroll
+    for (int t = 2; t < KM; ++t)
+        if (lane >= t * (t - 1) / 2) pair_t = t, pair_a = lane - t * (t - 1) / 2;
+    if (pair_a >= pair_t) pair_a = 0;   // lanes beyond the last pair
     const int ppt = (N + G * T - 1) / (G * T);
     const int first = (g * NW + wave) * (ppt * 64) + lane;   // sorted position of slot 0; slot j is 64 * j further on
     for (int b = group; b < B; b += ngroups) {
@@ -1195,25 +1227,23 @@ __global__ __launch_bounds__(kXT) void fps_sorted_kernel(const float* __restrict
         }
         float wmax = 1e10f;   // the wavefront's largest d (high word of its candidate key)
         int m = 1;            // centroids to apply this round
-        float ccx[KM], ccy[KM], ccz[KM];
+        float mcx, mcy, mcz;  // lane t: centroid t of the round
         {
             const int far = (int)start[b];
             const float* c = p + (int64_t)far * sn;
-            ccx[0] = c[0], ccy[0] = c[sc], ccz[0] = c[2 * sc];
-#pragma unroll
-            for (int t = 1; t < KM; ++t) ccx[t] = ccx[0], ccy[t] = ccy[0], ccz[t] = ccz[0];
+            mcx = c[0], mcy = c[sc], mcz = c[2 * sc];
             if (g == 0 && tid == 0) {
                 out_idx[(size_t)b * npoint] = far;
                 if (out_xyz) {
                     float* o = out_xyz + (size_t)b * npoint * 3;
-                    o[0] = ccx[0], o[1] = ccy[0], o[2] = ccz[0];
+                    o[0] = mcx, o[1] = mcy, o[2] = mcz;
                 }
             }
         }
         int count = 1;
         u64* gb = gran + (size_t)b * npoint * kGran * G;
 #ifdef PN2_FPS_DIAG
-        unsigned long long st[6] = {0, 0, 0, 0, 0, 0}, tprev = 0, nrounds = 0, ntouch = 0, tupd = 0, tsel = 0;
+        unsigned long long st[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0, nrounds = 0, ntouch = 0, tupd = 0, tsel = 0;
         const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime(), ct0 = __builtin_amdgcn_s_memtime();
 #endif
 
@@ -1223,26 +1253,30 @@ __global__ __launch_bounds__(kXT) void fps_sorted_kernel(const float* __restrict
             tprev = __builtin_amdgcn_s_memtime();
             ++nrounds;
 #endif
-            // ---- update with those of the m accepted centroids that can reach this wavefront's box
+            // ---- update with those of the m accepted centroids that can reach this wavefront's box: lane t tests centroid t,
+            // the touching ones are applied one by one from scalar registers
             bool touched = false;
+            {
+                const float bx = fmaxf(fmaxf(blo[0] - mcx, mcx - bhi[0]), 0.0f);
+                const float by = fmaxf(fmaxf(blo[1] - mcy, mcy - bhi[1]), 0.0f);
+                const float bz = fmaxf(fmaxf(blo[2] - mcz, mcz - bhi[2]), 0.0f);
+                const float bd = (bx * bx + by * by) + bz * bz;
+                const bool far_away = bd * (1.0f - 1.0f / 524288.0f) >= wmax;   // false for NaN: treated as touched
+                u64 reach = __ballot(lane < m && !far_away);
+                touched = reach != 0ull;
+                while (reach) {   // scalar
+                    const int t = (int)__builtin_ctzll(reach);
+                    reach &= reach - 1ull;
+                    const float cx = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(mcx), t));
+                    const float cy = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(mcy), t));
+                    const float cz = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(mcz), t));
+                    const f2 c2x = {cx, cx}, c2y = {cy, cy}, c2z = {cz, cz};
 #pragma unroll
-            for (int t = 0; t < KM; ++t) {
-                if (t < m) {
-                    const float bx = fmaxf(fmaxf(blo[0] - ccx[t], ccx[t] - bhi[0]), 0.0f);
-                    const float by = fmaxf(fmaxf(blo[1] - ccy[t], ccy[t] - bhi[1]), 0.0f);
-                    const float bz = fmaxf(fmaxf(blo[2] - ccz[t], ccz[t] - bhi[2]), 0.0f);
-                    const float bd = (bx * bx + by * by) + bz * bz;
-                    const bool far_away = bd * (1.0f - 1.0f / 524288.0f) >= wmax;   // false for NaN: treated as touched
-                    if (!far_away) {   // wave-uniform
-                        touched = true;
-                        const f2 c2x = {ccx[t], ccx[t]}, c2y = {ccy[t], ccy[t]}, c2z = {ccz[t], ccz[t]};
-#pragma unroll
-                        for (int q = 0; q < PPT / 2; ++q) {
-                            const f2 dx = x[q] - c2x, dy = y[q] - c2y, dz = z[q] - c2z;
-                            const f2 dist = (dx * dx + dy * dy) + dz * dz;
-                            d[q][0] = fminf(d[q][0], dist[0]);   // slots beyond N hold -1 and stay -1
-                            d[q][1] = fminf(d[q][1], dist[1]);
-                        }
+                    for (int q = 0; q < PPT / 2; ++q) {
+                        const f2 dx = x[q] - c2x, dy = y[q] - c2y, dz = z[q] - c2z;
+                        const f2 dist = (dx * dx + dy * dy) + dz * dz;
+                        d[q][0] = fminf(d[q][0], dist[0]);   // slots beyond N hold -1 and stay -1
+                        d[q][1] = fminf(d[q][1], dist[1]);
                     }
                 }
             }
@@ -1310,9 +1344,9 @@ __global__ __launch_bounds__(kXT) void fps_sorted_kernel(const float* __restrict
                 const u64 mine = lane < NW ? s_wkey[lane] : 0ull;
                 const unsigned mb = lane < NW ? s_wbound[lane] : 0u;
                 int o1;
-                const u64 best = wave_max_key_owner(mine, o1);
+                const u64 best = NW <= 8 ? max8_key_owner(mine, o1) : wave_max_key_owner(mine, o1);
                 const unsigned others = lane == o1 ? mb : max(mb, (unsigned)(mine >> 32));
-                const unsigned bound = pn2::wave_max_u32(others);
+                const unsigned bound = NW <= 8 ? max8_u32(others) : pn2::wave_max_u32(others);
                 if (lane == o1) {
                     u64* dst = slot + g;
                     const u64 v0 = best | kValid;
@@ -1358,8 +1392,9 @@ __global__ __launch_bounds__(kXT) void fps_sorted_kernel(const float* __restrict
                     }
                 }
                 STAMP(4);  // poll
+                const unsigned hbmax = pn2::wave_max_u32(hb);   // the members' bounds (independent of what follows)
                 // ---- ranks of all candidates at once: the keys go through LDS, lane l counts how many of HALF of them beat
-                // key (l & 31) [G <= 32; every lane against all of them otherwise], the halves are added through LDS again
+                // key (l & 31) [G <= 32; every lane against all of them otherwise], the halves meet through a lane swap
                 s_key[lane] = ek;
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
@@ -1370,67 +1405,66 @@ __global__ __launch_bounds__(kXT) void fps_sorted_kernel(const float* __restrict
                 if (split) {
 #pragma unroll
                     for (int jj = 0; jj < 16; ++jj) cnt += s_key[j0 + jj] > ckey ? 1u : 0u;
+                    const auto both = __builtin_amdgcn_permlane32_swap(cnt, cnt, false, false);
+                    cnt = both[0] + both[1];
                 } else {
 #pragma unroll 16
                     for (int jj = 0; jj < 64; ++jj) cnt += s_key[jj] > ckey ? 1u : 0u;
                 }
-                const unsigned hbmax = pn2::wave_max_u32(hb);
-                s_cnt[lane] = cnt;
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-                const unsigned rank = lane < G ? s_cnt[lane] + (split ? s_cnt[(lane & 31) + 32] : 0u) : 0xFFFFu;
+                STAMP(6);  // keys through LDS + counting
+                const unsigned rank = lane < G ? cnt : 0xFFFFu;
                 const int nz = __popcll(__ballot(ek != 0ull));   // candidates there are (ranks 0 .. nz-1 exist exactly once)
                 if (rank <= (unsigned)KM && ek != 0ull) {
-                    s_ckey[buf][rank] = ek;
-                    if (rank < (unsigned)KM) {
-                        s_cent[buf][rank][0] = __uint_as_float(ex);
-                        s_cent[buf][rank][1] = __uint_as_float(ey);
-                        s_cent[buf][rank][2] = __uint_as_float(ez);
-                    }
+                    ListEntry e;
+                    e.key = ek, e.x = __uint_as_float(ex), e.y = __uint_as_float(ey), e.z = __uint_as_float(ez), e.pad = 0.0f;
+                    s_list[buf][rank] = e;
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
-                // ---- accepted prefix: above H (certified next-largest) and untouched by the ones accepted before it
-                u64 tk[KM];
-                float tx[KM], ty[KM], tz[KM];
-#pragma unroll
-                for (int t = 0; t < KM; ++t) {
-                    tk[t] = t < nz ? s_ckey[buf][t] : 0ull;
-                    tx[t] = s_cent[buf][t][0], ty[t] = s_cent[buf][t][1], tz[t] = s_cent[buf][t][2];
-                }
+                STAMP(7);  // ranks, list into LDS
+                // ---- accepted prefix: candidate t is accepted while every one before it is, its key is above H (certified
+                // next-largest: H = the largest bound or key outside the list) and no earlier candidate lowers its distance.
+                // Lane p tests ONE (t, a) pair, lane t tests candidate t against H; the prefix falls out of two ballots.
                 u64 H = (((u64)hbmax) << 32) | 0xFFFFFFFFull;
                 if (KM < nz) {
-                    const u64 next = s_ckey[buf][KM];
+                    const u64 next = s_list[buf][KM].key;
                     H = next > H ? next : H;
                 }
+                const ListEntry et = s_list[buf][pair_t], ea = s_list[buf][pair_a];
+                const float pdx = __fsub_rn(et.x, ea.x), pdy = __fsub_rn(et.y, ea.y), pdz = __fsub_rn(et.z, ea.z);
+                const bool lowers = pn2::norm2(pdx, pdy, pdz) < __uint_as_float((unsigned)(et.key >> 32));
+                const u64 T = __ballot(lane < KM * (KM - 1) / 2 && lowers);
+                const u64 own = s_list[buf][lane < KM ? lane : 0].key;
+                const u64 A = __ballot(lane < KM && lane < nz && own > H);
+                STAMP(9);  // pair tests
                 int acc = 1;
 #pragma unroll
                 for (int t = 1; t < KM; ++t) {
-                    bool keep = acc == t && tk[t] != 0 && tk[t] > H;
-                    const float dt = __uint_as_float((unsigned)(tk[t] >> 32));
-#pragma unroll
-                    for (int a = 0; a < t; ++a) {
-                        const float dx = __fsub_rn(tx[t], tx[a]), dy = __fsub_rn(ty[t], ty[a]), dz = __fsub_rn(tz[t], tz[a]);
-                        keep = keep && !(pn2::norm2(dx, dy, dz) < dt);
-                    }
-                    if (keep) acc = t + 1;
+                    const u64 row = ((1ull << t) - 1ull) << (t * (t - 1) / 2);
+                    if (acc == t && ((A >> t) & 1ull) && (T & row) == 0ull) acc = t + 1;
                 }
                 if (acc > npoint - count) acc = npoint - count;
-                if (g == 0 && rank < (unsigned)acc && ek != 0ull && !dead) {
+                if (lane == 0) s_m[buf] = dead ? -1 : acc;   // -1: the launch is dead, everybody leaves after the barrier
+                STAMP(10);  // prefix
+                lds_barrier();
+                STAMP(8);  // barrier 2
+                if (g == 0 && rank < (unsigned)acc && ek != 0ull && !dead) {   // off the critical path: the others are released
                     const size_t o = (size_t)b * npoint + count + rank;
                     out_idx[o] = (int)(0xFFFFFFFFu - (unsigned)(ek & 0xFFFFFFFFull));
                     if (out_xyz)
                         out_xyz[o * 3] = __uint_as_float(ex), out_xyz[o * 3 + 1] = __uint_as_float(ey),
                                     out_xyz[o * 3 + 2] = __uint_as_float(ez);
                 }
-                if (lane == 0) s_m[buf] = dead ? -1 : acc;   // -1: the launch is dead, everybody leaves after the barrier
+                STAMP(5);  // result stores
+            } else {
+                lds_barrier();
             }
-            STAMP(5);  // ranks + list + chain (wave 0) / wait (others)
-            lds_barrier();
             m = s_m[buf];
             if (m < 0) return;    // dead launch (uniform: every thread reads the same word after the same barrier)
-#pragma unroll
-            for (int t = 0; t < KM; ++t) ccx[t] = s_cent[buf][t][0], ccy[t] = s_cent[buf][t][1], ccz[t] = s_cent[buf][t][2];
+            {
+                const ListEntry e = s_list[buf][lane < KM ? lane : 0];
+                mcx = e.x, mcy = e.y, mcz = e.z;
+            }
             count += m;
         }
 #ifdef PN2_FPS_DIAG
@@ -1444,6 +1478,7 @@ __global__ __launch_bounds__(kXT) void fps_sorted_kernel(const float* __restrict
             dbg[10] = ntouch;
             dbg[11] = tupd;
             dbg[12] = tsel;
+            dbg[13] = st[6], dbg[14] = st[7], dbg[15] = st[8], dbg[16] = st[9], dbg[17] = st[10];
         }
 #endif
         __syncthreads();
@@ -1554,7 +1589,7 @@ inline int sorted_km() {
         const int v = atoi(e);
         if (v == 4 || v == 8) return v;
     }
-    return 4;
+    return 8;   // measured on the 262144-point tree, 1024 samples: 1.02 ms with 4 picks per round at most, 0.87 ms with 8
 }
 
 // header + granules of the XCD kernels

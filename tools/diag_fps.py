@@ -22,9 +22,9 @@ for (N, npoint, B) in [(262144, 1024, 1), (65536, 1024, 8), (1024, 256, 1)]:
         assert st == 0
         torch.cuda.synchronize()
     xcd = 8192 < N <= 524288
-    d = (ws[64:64 + 104] if xcd else ws[16:16 + 64]).view(torch.int64).cpu().numpy()
+    d = (ws[64:64 + 144] if xcd else ws[16:16 + 64]).view(torch.int64).cpu().numpy()
     if xcd:
-        print("  (xcd kernel, local =", int(d[8]), ", rounds =", int(d[9]), ", rounds in which wavefront 0 of member 0 was touched =", int(d[10]), ", cycles per touched round: box+update", int(d[11]) // max(int(d[10]), 1), "select", int(d[12]) // max(int(d[10]), 1), ")")
+        print("  (xcd kernel, local =", int(d[8]), ", rounds =", int(d[9]), ", rounds in which wavefront 0 of member 0 was touched =", int(d[10]), ", cycles per touched round: box+update", int(d[11]) // max(int(d[10]), 1), "select", int(d[12]) // max(int(d[10]), 1), "; tail per round: rank count", int(d[13]) // int(d[9]), "bound+ranks+list", int(d[14]) // int(d[9]), "barrier2", int(d[15]) // int(d[9]), "list read", int(d[16]) // int(d[9]), "chain", int(d[17]) // int(d[9]), ")")
         npoint = max(int(d[9]), 1)          # per ROUND figures for the multi-pick kernel
     tot, rt = d[6], d[7]
     print(f"N={N} npoint={npoint} B={B}: {tot / npoint:.0f} cycles/step, clock {tot / (rt / 100.0):.0f} MHz, "
