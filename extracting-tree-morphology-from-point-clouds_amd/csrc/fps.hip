@@ -944,17 +944,20 @@ __global__ __launch_bounds__(kXT) void fps_multi_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Spatially ordered multi-pick rounds: the same exchange as fps_multi_kernel, but the update is skipped where it
-// provably changes nothing.
+// Spatially ordered multi-pick rounds: the granule exchange of fps_multi_kernel, but (1) the update is skipped where it
+// provably changes nothing, (2) a member lists two candidates and (3) the round's samples come from running the
+// sequential algorithm on the listed candidates (see fps_sorted_kernel).
 //
 // A new centroid c lowers d[p] only where |p - c|^2 < d[p].  If every point a wavefront holds lies in a box whose
 // distance to c is at least the wavefront's largest d, nothing it holds changes: its lanes' best-two, its published
-// candidate and its bound all stay what they were, and the wavefront goes straight to the barrier.  For that to be the
-// common case a wavefront has to hold NEIGHBOURS, so the cloud is put into Morton order first (64^3 cells of the cloud's
-// bounding cube; fps_box_kernel, fps_order_kernel and one radix sort of (cell << 20 | index) keys, ~60 us) and wavefront
-// w takes the w-th run of 64 * ppt sorted positions.  On the 262144-point tree a centroid touches ~12 of the 256
-// wavefronts after the first few dozen samples (tools/sim/fps_rounds.py), so a round is the serial exchange plus the
-// update and selection of ONE busy wavefront instead of two wavefronts per SIMD updating 16 points per lane each.
+// candidates and its bound all stay what they were, and the wavefront goes straight to the barrier.  For that to be the
+// common case a wavefront has to hold NEIGHBOURS, so the cloud is put into cell order first -- every axis of the cloud's
+// bounding box cut into 16, cells numbered along the Morton curve, one counting sort (fps_box_kernel, fps_hist_kernel,
+// fps_scatter_kernel: 22 us for 262144 points; a 38-bit radix sort of (cell, index) keys took 14 launches and 130 us) --
+// and wavefront w takes the w-th run of 64 * ppt sorted positions.  On the 262144-point tree a centroid reaches ~12 of
+// the 256 wavefronts after the first few dozen samples (tools/sim/fps_rounds.py), so a round is the serial exchange
+// plus the update and selection of the few busy wavefronts instead of two wavefronts per SIMD updating 16 points per
+// lane each.
 // The order only decides who holds which point: keys carry the ORIGINAL index, lanes compare full (d, ~index) keys
 // (slots are no longer in index order), so samples and tie-breaks are bit-identical to the unsorted kernels.
 // The box test is made safe against the rounding of both sides: the update computes fl((dx*dx + dy*dy) + dz*dz) with
@@ -1118,57 +1121,75 @@ __global__ __launch_bounds__(kOT) void fps_scatter_kernel(const float* __restric
     }
 }
 
-// Round of the ordered kernel (G <= 64 members, NW wavefronts each):
-//   every wavefront   box tests; if touched: update, lane best + runner-up (max / min trees over the slots, no serial
-//                     compare chain), wavefront candidate + bound into LDS                               -> barrier 1
-//   wavefront 0       workgroup candidate + bound, five granules published; polls all members' granules (lane l = member
-//                     l); ranks ALL candidates at once (keys through LDS, each lane counts the keys that beat "its" key
-//                     among half of the members) instead of KM dependent arg-max reductions; the candidates of rank
-//                     0 .. KM go to the list, the acceptance chain runs on it                               -> barrier 2
+// Round of the ordered kernel (NW wavefronts per member; PER listed candidates per member, G * PER <= 64):
+//   every wavefront   box tests (lane t tests centroid t); if touched: update, lane best + runner-up (max / min trees over
+//                     the slots), the wavefront's PER best lanes' points + a bound on everything else into LDS -> barrier 1
+//   wavefront 0       the member's PER best points + bound, 4 PER + 1 granules published; polls all members' granules
+//                     (lane l = candidate l >> 5 of member l & 31 for PER = 2); then SIMULATES the sequential algorithm on
+//                     the listed candidates: the largest listed key is the next sample as long as it is above H = the
+//                     largest bound (nothing unlisted can beat it -- keys only shrink), it lowers the other listed
+//                     candidates' distances exactly as the update will, and so on until the best listed key drops to H
+//                     or below.  The accepted samples go to LDS                                            -> barrier 2
 // Bounds travel as float bits only (low word taken as all ones): a bound may be loose, never low -- a loose one can
-// only shorten the accepted prefix, which the next round makes up for.
-// Max over lanes 0..7 (three row shifts instead of the six steps of a full wavefront reduction), result in every lane.
+// only shorten the accepted run, which the next round makes up for.  Two listed candidates per member matter: with one,
+// H is the largest runner-up of any member and stops the run after 3.4 samples on average; with two it is the largest
+// THIRD-best (5.4 samples per round, 191 rounds instead of 302 for 1024 samples of the 262144-point tree,
+// tools/sim/fps_listsim.py).
+struct alignas(16) ListEntry {
+    u64 key;
+    float x, y, z, pad;
+};
+constexpr int kCap = 16;   // samples accepted per round, at most
+
+// Max over lanes 0..7 / 0..15 (row shifts only), result in every lane.
 __device__ __forceinline__ unsigned max8_u32(unsigned v) {
     v = max(v, pn2::dpp_u32<0x111, 0xF>(0u, v));
     v = max(v, pn2::dpp_u32<0x112, 0xF>(0u, v));
     v = max(v, pn2::dpp_u32<0x114, 0xF>(0u, v));
     return (unsigned)__builtin_amdgcn_readlane((int)v, 7);
 }
-__device__ __forceinline__ u64 max8_key_owner(u64 k, int& owner) {
+__device__ __forceinline__ unsigned max16_u32(unsigned v) {
+    v = max(v, pn2::dpp_u32<0x111, 0xF>(0u, v));
+    v = max(v, pn2::dpp_u32<0x112, 0xF>(0u, v));
+    v = max(v, pn2::dpp_u32<0x114, 0xF>(0u, v));
+    v = max(v, pn2::dpp_u32<0x118, 0xF>(0u, v));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 15);
+}
+// largest key among lanes 0..W-1 (W = 8 or 16) and the lane that holds it
+template <int W>
+__device__ __forceinline__ u64 row_max_key_owner(u64 k, int& owner) {
     const unsigned hi = (unsigned)(k >> 32), lo = (unsigned)k;
-    const unsigned mh = max8_u32(hi);
-    u64 who = __ballot(hi == mh) & 0xFFull;
+    const u64 in = (1ull << W) - 1ull;
+    const unsigned mh = W == 8 ? max8_u32(hi) : max16_u32(hi);
+    u64 who = __ballot(hi == mh) & in;
     unsigned ml;
     if (__popcll(who) == 1) {
         owner = (int)__builtin_ctzll(who);
         ml = (unsigned)__builtin_amdgcn_readlane((int)lo, owner);
     } else {
-        ml = max8_u32(hi == mh ? lo : 0u);
-        who = __ballot(hi == mh && lo == ml) & 0xFFull;
+        const unsigned v = hi == mh ? lo : 0u;
+        ml = W == 8 ? max8_u32(v) : max16_u32(v);
+        who = __ballot(hi == mh && lo == ml) & in;
         owner = (int)__builtin_ctzll(who);
     }
     return ((u64)mh << 32) | ml;
 }
 
-struct alignas(16) ListEntry {
-    u64 key;
-    float x, y, z, pad;
-};
-
-template <int PPT, int KM>
+template <int PPT, int PER>
 __global__ __launch_bounds__(kXT) void fps_sorted_kernel(const float* __restrict__ xyz, int64_t sb, int64_t sn, int64_t sc,
                                                          int B, int N, int npoint, const int64_t* __restrict__ start,
                                                          const unsigned* __restrict__ order, int32_t* __restrict__ out_idx,
                                                          float* __restrict__ out_xyz, u64* gran, XcdHeader* hdr, int G,
                                                          Knobs kn) {
     constexpr int T = kXT, NW = T / 64;
-    constexpr int kGran = 5;  // granules per member and round: {key, x, y, z} of its best point + the bound
+    constexpr int kGran = 4 * PER + 1;  // granules per member and round: {key, x, y, z} of its PER best points + the bound
     static_assert(PPT <= 16, "slot numbers travel in four bits");
-    __shared__ u64 s_wkey[NW];        // a wavefront's candidate and bound: rewritten only in rounds that touch it
+    static_assert(PER == 1 || PER == 2, "one or two listed candidates per member");
+    static_assert(NW * PER <= 16, "the member's candidates are reduced inside one row of 16 lanes");
+    __shared__ u64 s_wkey[NW][PER];        // a wavefront's candidates and bound: rewritten only in rounds that touch it
+    __shared__ float s_wxyz[NW][PER][3];
     __shared__ unsigned s_wbound[NW];
-    __shared__ float s_wxyz[NW][3];
-    __shared__ u64 s_key[64];         // the members' candidates of this round, for the ranking
-    __shared__ ListEntry s_list[2][KM + 1];   // the round's candidates in rank order (+ the first one outside the list)
+    __shared__ ListEntry s_list[2][kCap];   // the round's accepted samples
     __shared__ int s_m[2];
     __shared__ int s_role[4];
     __shared__ float s_px[PPT * kXT], s_py[PPT * kXT], s_pz[PPT * kXT];
@@ -1183,14 +1204,11 @@ __global__ __launch_bounds__(kXT) void fps_sorted_kernel(const float* __restrict
     const bool local = s_role[3] != 0;
     if (group < 0 || ngroups <= 0) return;
 
-    static_assert(KM * (KM - 1) / 2 <= 64, "one lane per candidate pair");
-    int pair_t = 1, pair_a = 0;   // this lane's pair (t, a), a < t: lane = t (t - 1) / 2 + a
-#pragma unroll
-    for (int t = 2; t < KM; ++t)
-        if (lane >= t * (t - 1) / 2) pair_t = t, pair_a = lane - t * (t - 1) / 2;
-    if (pair_a >= pair_t) pair_a = 0;   // lanes beyond the last pair
     const int ppt = (N + G * T - 1) / (G * T);
     const int first = (g * NW + wave) * (ppt * 64) + lane;   // sorted position of slot 0; slot j is 64 * j further on
+    // the candidate this lane polls: candidate pc of member pm
+    const int pc = PER == 2 ? (lane >> 5) : 0, pm = PER == 2 ? (lane & 31) : lane;
+    const bool polls = pm < G;
     for (int b = group; b < B; b += ngroups) {
         const float* p = xyz + (int64_t)b * sb;
         const unsigned* ord = order + (size_t)b * N;
@@ -1289,7 +1307,7 @@ __global__ __launch_bounds__(kXT) void fps_sorted_kernel(const float* __restrict
 #ifdef PN2_FPS_DIAG
                 ++ntouch;
 #endif
-                // ---- this lane's best (exact key: slots are in Morton order, ties go to the lowest ORIGINAL index) and the
+                // ---- this lane's best (exact key: slots are in cell order, ties go to the lowest ORIGINAL index) and the
                 // largest d among its other slots, as max / min trees
                 float mx[PPT];
 #pragma unroll
@@ -1317,72 +1335,88 @@ __global__ __launch_bounds__(kXT) void fps_sorted_kernel(const float* __restrict
                 const int j1 = (int)(c1 & 15u);
                 const u64 k1 = m1 < 0.0f ? 0ull : (((u64)__float_as_uint(m1)) << 32) | (u64)(0xFFFFFFFFu - (c1 >> 4));
                 const unsigned b2 = m2 < 0.0f ? 0u : __float_as_uint(m2);
-                // ---- wavefront: best point (key + coordinates) and the float bits of the largest other d
-                int owner;
-                const u64 w1 = wave_max_key_owner(k1, owner);
-                const unsigned wb = pn2::wave_max_u32(lane == owner ? b2 : (unsigned)(k1 >> 32));
+                const float px = s_px[j1 * T + tid], py = s_py[j1 * T + tid], pz = s_pz[j1 * T + tid];
+                // ---- wavefront: the best points of PER different lanes (key + coordinates) and the float bits of the
+                // largest d among everything else (the other lanes' best points, every lane's runner-up)
+                int o1, o2 = -1;
+                const u64 w1 = wave_max_key_owner(k1, o1);
+                u64 w2 = 0;
+                if (PER == 2) w2 = wave_max_key_owner(lane == o1 ? 0ull : k1, o2);
+                const unsigned wb = pn2::wave_max_u32((lane == o1 || lane == o2) ? b2 : (unsigned)(k1 >> 32));
                 wmax = __uint_as_float((unsigned)(w1 >> 32));
-                if (lane == owner) {
-                    s_wkey[wave] = w1;
+                if (lane == o1) {
+                    s_wkey[wave][0] = w1;
                     s_wbound[wave] = wb;
-                    s_wxyz[wave][0] = s_px[j1 * T + tid];
-                    s_wxyz[wave][1] = s_py[j1 * T + tid];
-                    s_wxyz[wave][2] = s_pz[j1 * T + tid];
+                    s_wxyz[wave][0][0] = px, s_wxyz[wave][0][1] = py, s_wxyz[wave][0][2] = pz;
+                }
+                if (PER == 2 && lane == o2) {
+                    s_wkey[wave][PER - 1] = w2;
+                    s_wxyz[wave][PER - 1][0] = px, s_wxyz[wave][PER - 1][1] = py, s_wxyz[wave][PER - 1][2] = pz;
                 }
             }
 #ifdef PN2_FPS_DIAG
             if (touched) tsel += __builtin_amdgcn_s_memtime() - tu0;
 #endif
-            STAMP(1);  // lane best + runner-up, wavefront candidate
+            STAMP(1);  // lane best + runner-up, wavefront candidates
             lds_barrier();
             STAMP(2);  // barrier 1
             if (wave == 0) {
                 u64* slot = gb + (size_t)round * kGran * G;
                 const unsigned tag = (unsigned)(round + 1);
-                // ---- workgroup: its best point + the bound on everything else it holds (the other wavefronts' winners and
-                // every wavefront's bound); the lane that holds the best winner publishes all five granules
-                const u64 mine = lane < NW ? s_wkey[lane] : 0ull;
+                // ---- member: its PER best points among the wavefronts' candidates + the bound on everything else it holds
+                // (the other candidates and every wavefront's bound); the lanes that hold the winners publish
+                constexpr int W = NW * PER;   // candidates in lanes 0 .. W-1 (wavefront l / PER, candidate l % PER)
+                const int cw = lane < W ? lane / PER : 0, cc = lane < W ? lane % PER : 0;
+                const u64 mine = lane < W ? s_wkey[cw][cc] : 0ull;
                 const unsigned mb = lane < NW ? s_wbound[lane] : 0u;
-                int o1;
-                const u64 best = NW <= 8 ? max8_key_owner(mine, o1) : wave_max_key_owner(mine, o1);
-                const unsigned others = lane == o1 ? mb : max(mb, (unsigned)(mine >> 32));
-                const unsigned bound = NW <= 8 ? max8_u32(others) : pn2::wave_max_u32(others);
-                if (lane == o1) {
-                    u64* dst = slot + g;
-                    const u64 v0 = best | kValid;
-                    const u64 v1 = (((u64)tag) << 32) | (u64)__float_as_uint(s_wxyz[lane < NW ? lane : 0][0]);
-                    const u64 v2 = (((u64)tag) << 32) | (u64)__float_as_uint(s_wxyz[lane < NW ? lane : 0][1]);
-                    const u64 v3 = (((u64)tag) << 32) | (u64)__float_as_uint(s_wxyz[lane < NW ? lane : 0][2]);
+                const float qx = s_wxyz[cw][cc][0], qy = s_wxyz[cw][cc][1], qz = s_wxyz[cw][cc][2];
+                int o1, o2 = -1;
+                const u64 best = row_max_key_owner<(W <= 8 ? 8 : 16)>(mine, o1);
+                u64 best2 = 0;
+                if (PER == 2) best2 = row_max_key_owner<(W <= 8 ? 8 : 16)>(lane == o1 ? 0ull : mine, o2);
+                const unsigned rest = max((lane == o1 || lane == o2) ? 0u : (unsigned)(mine >> 32), mb);
+                const unsigned bound = W <= 8 ? max8_u32(rest) : max16_u32(rest);
+                // every candidate slot is published every round (a member with a single point left lists key 0 second)
+                const int pub2 = PER == 2 ? ((o2 < 0 || o2 == o1) ? ((o1 + 1) & 15) : o2) : -1;
+                if (lane == o1 || lane == pub2) {
+                    const int c = lane == o1 ? 0 : 1;
+                    u64* dst = slot + (size_t)(4 * c) * G + g;
+                    const u64 v0 = (c == 0 ? best : best2) | kValid;
+                    const u64 v1 = (((u64)tag) << 32) | (u64)__float_as_uint(qx);
+                    const u64 v2 = (((u64)tag) << 32) | (u64)__float_as_uint(qy);
+                    const u64 v3 = (((u64)tag) << 32) | (u64)__float_as_uint(qz);
                     const u64 v4 = (((u64)bound) << 32) | 0xFFFFFFFFull | kValid;
+                    u64* bdst = slot + (size_t)(4 * PER) * G + g;
                     if (local) {
                         __hip_atomic_store(dst, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         __hip_atomic_store(dst + G, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         __hip_atomic_store(dst + 2 * G, v2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         __hip_atomic_store(dst + 3 * G, v3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_store(dst + 4 * G, v4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (c == 0) __hip_atomic_store(bdst, v4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     } else {
                         st_granule(dst, v0);
                         st_granule(dst + G, v1);
                         st_granule(dst + 2 * G, v2);
                         st_granule(dst + 3 * G, v3);
-                        st_granule(dst + 4 * G, v4);
+                        if (c == 0) st_granule(bdst, v4);
                     }
                 }
-                STAMP(3);  // workgroup candidate + publish
-                // ---- poll: lane l reads the five granules of member l
+                STAMP(3);  // member candidates + publish
+                // ---- poll: lane l reads the four granules of candidate pc of member pm and the member's bound
                 u64 ek = 0;
                 unsigned hb = 0, ex = 0, ey = 0, ez = 0;
                 bool dead = false;
                 {
-                    const u64* src0 = slot + (lane < G ? lane : 0);
+                    const u64* src0 = slot + (size_t)(4 * pc) * G + (polls ? pm : 0);
+                    const u64* srcb = slot + (size_t)(4 * PER) * G + (polls ? pm : 0);
                     unsigned spins = 0;
                     for (;;) {
                         const u64 v0 = ld_granule(src0), v1 = ld_granule(src0 + G), v2 = ld_granule(src0 + 2 * G),
-                                  v3 = ld_granule(src0 + 3 * G), v4 = ld_granule(src0 + 4 * G);
+                                  v3 = ld_granule(src0 + 3 * G), v4 = ld_granule(srcb);
                         const bool ok = ((v0 & kValid) != 0) & ((unsigned)(v1 >> 32) == tag) & ((unsigned)(v2 >> 32) == tag) &
                                         ((unsigned)(v3 >> 32) == tag) & ((v4 & kValid) != 0);
-                        ek = lane < G ? (v0 & ~kValid) : 0ull;
-                        hb = lane < G ? (unsigned)((v4 & ~kValid) >> 32) : 0u;
+                        ek = polls ? (v0 & ~kValid) : 0ull;
+                        hb = polls ? (unsigned)((v4 & ~kValid) >> 32) : 0u;
                         ex = (unsigned)v1, ey = (unsigned)v2, ez = (unsigned)v3;
                         if (__all(ok)) break;
                         if (!spin_alive(spins, kn, &hdr->err, kStatusHandoff)) {  // wave-uniform
@@ -1392,77 +1426,65 @@ __global__ __launch_bounds__(kXT) void fps_sorted_kernel(const float* __restrict
                     }
                 }
                 STAMP(4);  // poll
-                const unsigned hbmax = pn2::wave_max_u32(hb);   // the members' bounds (independent of what follows)
-                // ---- ranks of all candidates at once: the keys go through LDS, lane l counts how many of HALF of them beat
-                // key (l & 31) [G <= 32; every lane against all of them otherwise], the halves meet through a lane swap
-                s_key[lane] = ek;
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-                const bool split = G <= 32;   // scalar
-                const int ci = split ? (lane & 31) : lane, j0 = split ? (lane >> 5) * 16 : 0;
-                const u64 ckey = s_key[ci];
-                unsigned cnt = 0;
-                if (split) {
-#pragma unroll
-                    for (int jj = 0; jj < 16; ++jj) cnt += s_key[j0 + jj] > ckey ? 1u : 0u;
-                    const auto both = __builtin_amdgcn_permlane32_swap(cnt, cnt, false, false);
-                    cnt = both[0] + both[1];
-                } else {
-#pragma unroll 16
-                    for (int jj = 0; jj < 64; ++jj) cnt += s_key[jj] > ckey ? 1u : 0u;
+                // ---- the sequential algorithm on the listed candidates
+                const unsigned hbmax = pn2::wave_max_u32(hb);
+                // (a key is above H = (hbmax, all ones) exactly when its distance bits are above hbmax; the distance bits
+                // and the index word are kept apart so that a step is one 32-bit reduction, one ballot, four readlanes)
+                const float fx = __uint_as_float(ex), fy = __uint_as_float(ey), fz = __uint_as_float(ez);
+                const unsigned klo = (unsigned)ek;
+                unsigned chi = (unsigned)(ek >> 32);
+                bool alive = ek != 0ull;
+                int mypos = -1;         // the position this lane's candidate was accepted at
+                unsigned mypos_hi = 0;  // ... and its distance bits at that moment
+                int acc = 0;
+                const int room = npoint - count < kCap ? npoint - count : kCap;
+                for (;;) {
+                    const unsigned mh = pn2::wave_max_u32(alive ? chi : 0u);
+                    u64 who = __ballot(alive && chi == mh);
+                    if (who == 0ull || acc >= room || (acc > 0 && mh <= hbmax)) break;   // scalar
+                    if (who & (who - 1ull)) {   // equal distances: the lowest original index (largest low word) wins
+                        const unsigned ml = pn2::wave_max_u32((alive && chi == mh) ? klo : 0u);
+                        who = __ballot(alive && chi == mh && klo == ml);
+                    }
+                    const int o = (int)__builtin_ctzll(who);
+                    const float cx = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)ex, o));
+                    const float cy = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)ey, o));
+                    const float cz = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)ez, o));
+                    const bool me = lane == o;
+                    mypos = me ? acc : mypos;
+                    mypos_hi = me ? mh : mypos_hi;
+                    alive = alive && !me;
+                    // what the update with this sample will do to the other listed points (same expression, same bits)
+                    const f2 px2 = {fx, fx}, py2 = {fy, fy}, pz2 = {fz, fz};
+                    const f2 c2x = {cx, cx}, c2y = {cy, cy}, c2z = {cz, cz};
+                    const f2 dx = px2 - c2x, dy = py2 - c2y, dz = pz2 - c2z;
+                    const f2 dist = (dx * dx + dy * dy) + dz * dz;
+                    chi = __float_as_uint(fminf(__uint_as_float(chi), dist[0]));
+                    ++acc;
                 }
-                STAMP(6);  // keys through LDS + counting
-                const unsigned rank = lane < G ? cnt : 0xFFFFu;
-                const int nz = __popcll(__ballot(ek != 0ull));   // candidates there are (ranks 0 .. nz-1 exist exactly once)
-                if (rank <= (unsigned)KM && ek != 0ull) {
+                if (mypos >= 0) {
                     ListEntry e;
-                    e.key = ek, e.x = __uint_as_float(ex), e.y = __uint_as_float(ey), e.z = __uint_as_float(ez), e.pad = 0.0f;
-                    s_list[buf][rank] = e;
+                    e.key = (((u64)mypos_hi) << 32) | (u64)klo, e.x = fx, e.y = fy, e.z = fz, e.pad = 0.0f;
+                    s_list[buf][mypos] = e;
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-                STAMP(7);  // ranks, list into LDS
-                // ---- accepted prefix: candidate t is accepted while every one before it is, its key is above H (certified
-                // next-largest: H = the largest bound or key outside the list) and no earlier candidate lowers its distance.
-                // Lane p tests ONE (t, a) pair, lane t tests candidate t against H; the prefix falls out of two ballots.
-                u64 H = (((u64)hbmax) << 32) | 0xFFFFFFFFull;
-                if (KM < nz) {
-                    const u64 next = s_list[buf][KM].key;
-                    H = next > H ? next : H;
-                }
-                const ListEntry et = s_list[buf][pair_t], ea = s_list[buf][pair_a];
-                const float pdx = __fsub_rn(et.x, ea.x), pdy = __fsub_rn(et.y, ea.y), pdz = __fsub_rn(et.z, ea.z);
-                const bool lowers = pn2::norm2(pdx, pdy, pdz) < __uint_as_float((unsigned)(et.key >> 32));
-                const u64 T = __ballot(lane < KM * (KM - 1) / 2 && lowers);
-                const u64 own = s_list[buf][lane < KM ? lane : 0].key;
-                const u64 A = __ballot(lane < KM && lane < nz && own > H);
-                STAMP(9);  // pair tests
-                int acc = 1;
-#pragma unroll
-                for (int t = 1; t < KM; ++t) {
-                    const u64 row = ((1ull << t) - 1ull) << (t * (t - 1) / 2);
-                    if (acc == t && ((A >> t) & 1ull) && (T & row) == 0ull) acc = t + 1;
-                }
-                if (acc > npoint - count) acc = npoint - count;
                 if (lane == 0) s_m[buf] = dead ? -1 : acc;   // -1: the launch is dead, everybody leaves after the barrier
-                STAMP(10);  // prefix
+                STAMP(6);  // simulation
                 lds_barrier();
                 STAMP(8);  // barrier 2
-                if (g == 0 && rank < (unsigned)acc && ek != 0ull && !dead) {   // off the critical path: the others are released
-                    const size_t o = (size_t)b * npoint + count + rank;
-                    out_idx[o] = (int)(0xFFFFFFFFu - (unsigned)(ek & 0xFFFFFFFFull));
-                    if (out_xyz)
-                        out_xyz[o * 3] = __uint_as_float(ex), out_xyz[o * 3 + 1] = __uint_as_float(ey),
-                                    out_xyz[o * 3 + 2] = __uint_as_float(ez);
+                if (g == 0 && lane < acc && !dead) {   // off the critical path: the others are released
+                    const ListEntry e = s_list[buf][lane];
+                    const size_t o = (size_t)b * npoint + count + lane;
+                    out_idx[o] = (int)(0xFFFFFFFFu - (unsigned)(e.key & 0xFFFFFFFFull));
+                    if (out_xyz) out_xyz[o * 3] = e.x, out_xyz[o * 3 + 1] = e.y, out_xyz[o * 3 + 2] = e.z;
                 }
                 STAMP(5);  // result stores
             } else {
                 lds_barrier();
             }
             m = s_m[buf];
-            if (m < 0) return;    // dead launch (uniform: every thread reads the same word after the same barrier)
+            if (m <= 0) return;    // dead launch (uniform: every thread reads the same word after the same barrier)
             {
-                const ListEntry e = s_list[buf][lane < KM ? lane : 0];
+                const ListEntry e = s_list[buf][lane < kCap ? lane : 0];
                 mcx = e.x, mcy = e.y, mcz = e.z;
             }
             count += m;
@@ -1584,17 +1606,17 @@ inline OrderLayout order_layout(size_t head, int B, int N) {
 inline bool use_sorted(int B, int N) {
     return getenv("PN2_FPS_NO_SORT") == nullptr && N < (1 << 27) && B <= 4096 && multi_group_size(N) <= 64;
 }
-inline int sorted_km() {
-    if (const char* e = getenv("PN2_FPS_KM")) {
-        const int v = atoi(e);
-        if (v == 4 || v == 8) return v;
-    }
-    return 8;   // measured on the 262144-point tree, 1024 samples: 1.02 ms with 4 picks per round at most, 0.87 ms with 8
+// listed candidates per member: two while 2 G candidates fit one wavefront (PN2_FPS_PER=1: A/B aid)
+inline int sorted_per(int N) {
+    if (const char* e = getenv("PN2_FPS_PER"))
+        if (atoi(e) == 1) return 1;
+    return multi_group_size(N) <= 32 ? 2 : 1;
 }
 
 // header + granules of the XCD kernels
 inline size_t xcd_plain_bytes(int B, int N, int npoint) {
-    if (use_multi_pick(N, npoint)) return sizeof(XcdHeader) + (size_t)B * npoint * 5 * multi_group_size(N) * sizeof(u64);
+    if (use_multi_pick(N, npoint))   // 4 PER + 1 granules per (cloud, round, member): 9 for the ordered kernel with two candidates
+        return sizeof(XcdHeader) + (size_t)B * npoint * (multi_group_size(N) <= 32 ? 9 : 5) * multi_group_size(N) * sizeof(u64);
     return sizeof(XcdHeader) + (size_t)B * npoint * 4 * xcd_group_size(N) * (xcd_perwave(N) ? kXT / 64 : 1) * sizeof(u64);
 }
 
@@ -1638,17 +1660,17 @@ extern "C" int pn2_fps_f32(const float* xyz, int64_t sb, int64_t sn, int64_t sc,
                 hipLaunchKernelGGL(fps_scatter_kernel, grid, dim3(kOT), 0, s, xyz, sb, sn, sc, N, box, total, cursor, order);
             }
             const double fb = (double)B * (12.0 * N + 8.0 * npoint);
-            const int km = sorted_km();
+            const int per = sorted_per(N);
 #define PN2_FPS_SORTED(P, K)                                                                                                     \
-    if (ppt == P && km == K)                                                                                                      \
+    if (ppt == P && per == K)                                                                                                     \
         PN2_LAUNCH("fps", fb, 0, (fps_sorted_kernel<P, K>), dim3(kXGrid), dim3(kXT), s, xyz, sb, sn, sc, B, N, npoint, start,      \
                    (const unsigned*)order, out_idx, out_xyz, gran, hdr, G, kn);
-            PN2_FPS_SORTED(4, 4)
-            PN2_FPS_SORTED(8, 4)
-            PN2_FPS_SORTED(16, 4)
-            PN2_FPS_SORTED(4, 8)
-            PN2_FPS_SORTED(8, 8)
-            PN2_FPS_SORTED(16, 8)
+            PN2_FPS_SORTED(4, 1)
+            PN2_FPS_SORTED(8, 1)
+            PN2_FPS_SORTED(16, 1)
+            PN2_FPS_SORTED(4, 2)
+            PN2_FPS_SORTED(8, 2)
+            PN2_FPS_SORTED(16, 2)
 #undef PN2_FPS_SORTED
             PN2_LAUNCH_CHECK();
             return 0;

@@ -14,8 +14,8 @@ for (N, npoint, B) in cases:
     x = torch.from_numpy(xyz.transpose(0, 2, 1).copy()).cuda()
     start = torch.arange(B, dtype=torch.long, device="cuda") * 7
     out = {}
-    for tag, env in (("index", {"PN2_FPS_NO_SORT": "1"}), ("morton4", {"PN2_FPS_KM": "4"}), ("morton8", {"PN2_FPS_KM": "8"})):
-        for k in ("PN2_FPS_NO_SORT", "PN2_FPS_KM"):
+    for tag, env in (("index", {"PN2_FPS_NO_SORT": "1"}), ("morton4", {"PN2_FPS_PER": "1"}), ("morton8", {})):
+        for k in ("PN2_FPS_NO_SORT", "PN2_FPS_PER"):
             os.environ.pop(k, None)
         os.environ.update(env)
         idx = torch.empty(B, npoint, dtype=torch.int32, device="cuda")
@@ -38,5 +38,5 @@ for (N, npoint, B) in cases:
         out[tag] = (e0.elapsed_time(e1) / 10 * 1e3, idx.cpu(), nxyz.cpu())
     same4 = torch.equal(out["index"][1], out["morton4"][1]) and torch.equal(out["index"][2], out["morton4"][2])
     same8 = torch.equal(out["index"][1], out["morton8"][1]) and torch.equal(out["index"][2], out["morton8"][2])
-    print(f"N={N} npoint={npoint} B={B}: index order {out['index'][0]:.1f} us, morton K=4 {out['morton4'][0]:.1f} us (same={same4}), "
-          f"K=8 {out['morton8'][0]:.1f} us (same={same8})", flush=True)
+    print(f"N={N} npoint={npoint} B={B}: index order {out['index'][0]:.1f} us, cell order, 1 listed per member {out['morton4'][0]:.1f} us (same={same4}), "
+          f"2 listed {out['morton8'][0]:.1f} us (same={same8})", flush=True)

@@ -47,3 +47,37 @@ while count < S:
     count += len(acc)
     hist.append(len(acc))
 print(f"G={G} listed/member={PER} cap={CAP}: rounds {rounds}, picks/round {np.mean(hist):.2f}, max {max(hist)}")
+
+# ---- variant: two listed per member, but taken from DIFFERENT wavefronts (each wavefront lists only its best point)
+def variant_distinct_waves(NWV=8):
+    d = np.full(N, 1e10, np.float32)
+    d = np.minimum(d, ((P - P[0]) ** 2).sum(1))
+    count, rounds, hist = 1, 0, []
+    wspan = span // NWV
+    while count < S:
+        rounds += 1
+        dw = d.reshape(G, NWV, wspan)
+        ia = np.argsort(-dw, axis=2)[:, :, :2]
+        best = np.take_along_axis(dw, ia[:, :, :1], 2)[:, :, 0]        # [G, NWV]
+        second = np.take_along_axis(dw, ia[:, :, 1:2], 2)[:, :, 0]
+        bidx = ia[:, :, 0] + np.arange(NWV)[None, :] * wspan + np.arange(G)[:, None] * span
+        wo = np.argsort(-best, axis=1)
+        cand = np.take_along_axis(bidx, wo[:, :2], 1).ravel()
+        third = np.take_along_axis(best, wo[:, 2:3], 1)[:, 0]
+        H = max(third.max(), second.max())
+        cd = d[cand].copy()
+        acc = []
+        while len(acc) < min(16, S - count):
+            j = int(np.argmax(cd))
+            if acc and not cd[j] > H:
+                break
+            acc.append(cand[j])
+            cd = np.minimum(cd, ((P[cand] - P[cand[j]]) ** 2).sum(1))
+        for a in acc:
+            d = np.minimum(d, ((P - P[a]) ** 2).sum(1))
+        count += len(acc)
+        hist.append(len(acc))
+    print(f"distinct-wavefront variant: rounds {rounds}, picks/round {np.mean(hist):.2f}")
+
+if G == 32 and PER == 2:
+    variant_distinct_waves()
