@@ -471,11 +471,32 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     __shared__ double s_mean;
     const int c = blockIdx.x, t = threadIdx.x;
     const int nchunk = (rows + CH - 1) / CH;
+    // Up to KEEP chunks per thread stay in registers between the two reductions (the strided partials are read once:
+    // one useful float per cache line, the read IS the kernel's time); longer columns re-read.
+    constexpr int KEEP = 16;
+    const bool keep = nchunk <= KEEP * 256;   // uniform
+    float pm[KEEP], pv[KEEP];
     double acc = 0.0;
+    if (keep) {
+#pragma unroll
+        for (int i = 0; i < KEEP; ++i) {
+            const int k = t + 256 * i;
+            const bool on = k < nchunk;
+            pm[i] = on ? partial[((long long)k * 2) * C + c] : 0.0f;
+            pv[i] = on ? partial[((long long)k * 2 + 1) * C + c] : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < KEEP; ++i) {
+            const int k = t + 256 * i;
+            const int n = k < nchunk ? (rows - k * CH < CH ? rows - k * CH : CH) : 0;
+            acc += (double)n * (double)pm[i];
+        }
+    } else {
 #pragma unroll 8
-    for (int k = t; k < nchunk; k += 256) {  // independent strided loads: keep several in flight
-        const int n = rows - k * CH < CH ? rows - k * CH : CH;
-        acc += (double)n * (double)partial[((long long)k * 2) * C + c];
+        for (int k = t; k < nchunk; k += 256) {  // independent strided loads: keep several in flight
+            const int n = rows - k * CH < CH ? rows - k * CH : CH;
+            acc += (double)n * (double)partial[((long long)k * 2) * C + c];
+        }
     }
     red[t] = acc;
     __syncthreads();
@@ -487,11 +508,23 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     __syncthreads();
     const double mean = s_mean;
     acc = 0.0;
+    if (keep) {
+#pragma unroll
+        for (int i = 0; i < KEEP; ++i) {
+            const int k = t + 256 * i;
+            if (k < nchunk) {
+                const int n = rows - k * CH < CH ? rows - k * CH : CH;
+                const double d = (double)pm[i] - mean;
+                acc += (double)pv[i] + (double)n * d * d;
+            }
+        }
+    } else {
 #pragma unroll 8
-    for (int k = t; k < nchunk; k += 256) {
-        const int n = rows - k * CH < CH ? rows - k * CH : CH;
-        const double d = (double)partial[((long long)k * 2) * C + c] - mean;
-        acc += (double)partial[((long long)k * 2 + 1) * C + c] + (double)n * d * d;
+        for (int k = t; k < nchunk; k += 256) {
+            const int n = rows - k * CH < CH ? rows - k * CH : CH;
+            const double d = (double)partial[((long long)k * 2) * C + c] - mean;
+            acc += (double)partial[((long long)k * 2 + 1) * C + c] + (double)n * d * d;
+        }
     }
     __syncthreads();
     red[t] = acc;
