@@ -29,7 +29,7 @@ sys.path.insert(0, REPO)
 from __graft_entry__ import load_pkg  # noqa: E402
 
 # library kernel name -> substring of the device kernel name in the PMC traffic summary (tools/pmc_traffic.py)
-PMC_NAMES = {"fps": "fps_multi_kernel", "gemm_fwd": "gemm_kernel<true, 1, true, 0, 0, 128", "gemm_dgrad": "gemm_kernel<true, 2, false, 0, 1, 128",
+PMC_NAMES = {"fps": "fps_sorted_kernel", "gemm_fwd": "gemm_kernel<true, 1, true, 0, 0, 128", "gemm_dgrad": "gemm_kernel<true, 2, false, 0, 1, 128",
              "gemm_wgrad": "gemm_kernel<false, 2, false, 1, 2, 128", "three_interpolate_grad": "tig_reduce_kernel",
              "ball_query": "ball_query_kernel", "three_nn": "three_nn_kernel", "narrow_bwd": "narrow_bwd_kernel",
              "narrow_fwd": "narrow_fwd_kernel"}
