@@ -105,7 +105,9 @@ def _cloud(B, N, seed, scale=1.0, shift=(0, 0, 0)):
 
 
 FPS_MODES = {"no_xcd": {"PN2_FPS_NO_XCD": 1}, "no_multi": {"PN2_FPS_NO_MULTI": 1}, "fallback": {"PN2_FPS_FORCE_FALLBACK": 1},
-             "fallback_no_multi": {"PN2_FPS_FORCE_FALLBACK": 1, "PN2_FPS_NO_MULTI": 1}}
+             "fallback_no_multi": {"PN2_FPS_FORCE_FALLBACK": 1, "PN2_FPS_NO_MULTI": 1},
+             # multi-pick rounds in index order (round 1's kernel), and the ordered kernel with one listed candidate per member
+             "no_sort": {"PN2_FPS_NO_SORT": 1}, "one_listed": {"PN2_FPS_PER": 1}}
 
 
 @pytest.mark.gpu
@@ -125,6 +127,42 @@ def test_fps_variants_vs_oracle(pn2, mode, B, N, npoint):
     with env(**FPS_MODES[mode]):
         got, new_xyz = ops.furthest_point_sample(dev(xyz), npoint, dev(start))
         ops.check_status()
+    assert np.array_equal(got.cpu().numpy(), want)
+    assert np.array_equal(new_xyz.cpu().numpy(), O.index_points(xyz, want))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["identical", "flat", "two_places", "many_clouds", "lattice", "few_distinct", "huge_offset"])
+def test_fps_ordered_kernel_edges(pn2, case):
+    """The spatially ordered multi-pick kernel (cell counting sort, box-test skips, two listed candidates per member,
+    sequential simulation on the list) on inputs that stress its shortcuts: degenerate boxes, exact distance ties inside and
+    across wavefronts and members, distances that reach zero, more clouds than groups, coordinates far from the origin."""
+    from pn2_amd import ops
+    O.build()
+    rng = np.random.default_rng(11)
+    B, N, npoint = 2, 20000, 256
+    if case == "identical":
+        xyz = np.tile(np.array([[1.5, -2.0, 3.25]], np.float32), (B, N, 1))
+    elif case == "flat":
+        xyz = _cloud(B, N, seed=5)
+        xyz[:, :, 2] = 7.0
+    elif case == "two_places":
+        xyz = np.where(rng.integers(0, 2, size=(B, N, 1)) == 0, np.float32([0.0, 0.0, 0.0]), np.float32([1.0, 2.0, 3.0])).astype(np.float32)
+    elif case == "many_clouds":
+        B, N, npoint = 11, 65536, 200                      # 32 members per cloud, 8 groups: some groups own two clouds
+        xyz = _cloud(B, N, seed=6, scale=2.0)
+    elif case == "lattice":
+        xyz = (np.round(_cloud(B, N, seed=7, scale=1.5) * 2.0) / 2.0).astype(np.float32)   # half-metre lattice: ties everywhere
+    elif case == "few_distinct":
+        B, N, npoint = 1, 17000, 300
+        places = _cloud(1, 100, seed=8)[0]
+        xyz = places[rng.integers(0, 100, size=(B, N))]
+    else:
+        xyz = _cloud(B, N, seed=9, scale=0.3, shift=(4.0e5, -3.0e5, 250.0))   # UTM-like coordinates: coarse fp32 grid
+    start = rng.integers(0, N, size=B)
+    want = O.farthest_point_sample(xyz, npoint, start)
+    got, new_xyz = ops.furthest_point_sample(dev(xyz), npoint, dev(start))
+    ops.check_status()
     assert np.array_equal(got.cpu().numpy(), want)
     assert np.array_equal(new_xyz.cpu().numpy(), O.index_points(xyz, want))
 
