@@ -14,7 +14,7 @@ import torch.nn.functional as F
 
 from .. import ops, streaming
 from ..Loss import MaskedPointLoss, point_wise_loss
-from ..mlp import batched_counters
+from ..mlp import batched_counters, chain_pair_rows
 from ..Utils import cuda_cast
 from .blocks import (MLP, ConvHead, PointNetFeaturePropagation, PointNetSetAbstraction,
                      PointNetSetAbstractionMsg)
@@ -83,8 +83,7 @@ class PointNet2(nn.Module):
         output = dict()
         with batched_counters():        # one launch for all BatchNorm step counters of the pass
             output["backbone_feats"] = self.forward_backbone(coords=batch["coords"], feats=batch["feats"])
-            output["semantic_prediction_logits"] = self.semantic_linear(output["backbone_feats"])
-            output["offset_predictions"] = self.offset_linear(output["backbone_feats"])
+            output["semantic_prediction_logits"], output["offset_predictions"] = self._heads(output["backbone_feats"])
         if return_loss:
             output = self.get_loss(model_output=output, **batch)
         return output
@@ -103,6 +102,14 @@ class PointNet2(nn.Module):
             for level in range(n, 1, -1):
                 pts[level - 1] = getattr(self, f"fp{level}")(xyz[level - 1], xyz[level], pts[level - 1], pts[level])
             return self.fp1(xyz[0], xyz[1], None, pts[1])
+
+    def _heads(self, feats):
+        """feats [B,128,N] -> (semantic logits [B,2,N], offsets [B,3,N]): the two ConvHeads (reference lines 128-129) as one
+        autograd node, so that their common input gets ONE gradient tensor instead of two and a sum."""
+        B, C, N = feats.shape
+        rows = feats.permute(0, 2, 1).reshape(B * N, C)
+        sem, off = chain_pair_rows(rows, self.semantic_linear._layers(), self.offset_linear._layers())
+        return sem.view(B, N, -1).permute(0, 2, 1), off.view(B, N, -1).permute(0, 2, 1)
 
     @staticmethod
     def _valid_rows(sem_logits, off_preds, masks_pad, masks_off):
@@ -166,8 +173,7 @@ class PointNet2(nn.Module):
         valid semantic rows, the valid+masked offset rows and the global point ids of both."""
         feats = self.forward_backbone(coords=mini_batch["coords"], feats=mini_batch["feats"])
         with torch.amp.autocast("cuda", enabled=False):
-            sem_logits = self.semantic_linear(feats)
-            off_preds = self.offset_linear(feats)
+            sem_logits, off_preds = self._heads(feats)
         dev = feats.device          # the reference's collate hands over host tensors; its x[mask] indexing accepts them
         masks_pad, masks_off = mini_batch["masks_pad"].to(dev), mini_batch["masks_off"].to(dev)
         sem, off = self._valid_rows(sem_logits, off_preds, masks_pad, masks_off)

@@ -96,7 +96,8 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 2                      # PN2_ABI_VERSION of include/pn2_hip.h
+ABI_VERSION = 3                      # PN2_ABI_VERSION of include/pn2_hip.h
+CHAIN_ACCUMULATE_DX = 0x100          # PN2_CHAIN_ACCUMULATE_DX
 STATUS_FPS_HANDOFF, STATUS_FPS_ARRIVAL, STATUS_BAD_INDEX = 1, 2, 4   # PN2_STATUS_* bits
 
 

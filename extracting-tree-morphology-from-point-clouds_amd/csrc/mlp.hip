@@ -217,6 +217,7 @@ struct GemmArgs {
     long long ldey;
     const float* ecoef;
     int erelu;
+    int accumulate;       // EPI_STORE: C += result (PN2_CHAIN_ACCUMULATE_DX)
 };
 
 // TILE = 128: four waves own 64 x 64 each (2 x 2 MFMA accumulators); TILE = 64: 32 x 32 each (one accumulator),
@@ -249,7 +250,10 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& g, f32x16 (&a
                 const float val = acc[i][j][r] + bias;
                 acc[i][j][r] = val;
                 if (FULL || row < g.M) {
-                    if (cok) C[(long long)row * g.ldc + col] = val;
+                    if (cok) {
+                        float* c = C + (long long)row * g.ldc + col;
+                        *c = (EPI == EPI_STORE && g.accumulate) ? *c + val : val;
+                    }
                     sum += val;
                     ++cnt;
                 }
@@ -1606,7 +1610,10 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
                                      int precision, void* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !layers || nlayers <= 0 || rows <= 0 || !dout || !scratch_a || !scratch_b) return PN2_E_BADARG;
     if (dx_first_col < 0 || dx_first_col >= layers[0].cin) return PN2_E_BADARG;
+    const int accumulate_dx = (precision & PN2_CHAIN_ACCUMULATE_DX) ? 1 : 0;
+    precision &= ~PN2_CHAIN_ACCUMULATE_DX;
     if (precision != PN2_PRECISION_F32 && precision != PN2_PRECISION_BF16) return PN2_E_BADARG;
+    if (accumulate_dx && !dx) return PN2_E_BADARG;
     t_precision = precision;
     if (!segs_valid(rows, segments, pool_k)) return PN2_E_BADARG;
     const Segs S = make_segs(rows, segments);
@@ -1673,7 +1680,7 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
             float* part_w = part_s + (size_t)nblk * 2 * L.cin;
             float* part_b = part_w + (size_t)nblk * L.cout * L.cin;
             float* target = i > 0 ? bufs[which] : (dx ? dx : bufs[which]);
-            if (i == 0 && dx && lddx != L.cin) return PN2_E_BADARG;
+            if (i == 0 && dx && (lddx != L.cin || accumulate_dx)) return PN2_E_BADARG;   // the narrow kernel stores
             int st = launch_narrow_bwd(in, rows, L, dz, target, part_s, part_w, part_b, tb, nblk, s);
             if (st) return st;
             if (L.dweight)
@@ -1740,6 +1747,7 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
             g.K = L.cout;
             g.C = target;
             g.ldc = ldt;
+            g.accumulate = i == 0 ? accumulate_dx : 0;
             const int tile = pick_tile(rows, L.cin - skip, 1);
             if (i > 0 && layers[i - 1].has_bn) {
                 g.partial = ws;

@@ -164,9 +164,14 @@ class _ChainFn(torch.autograd.Function):
         maxc = max(maxc, cin)
         skip = int(meta.get("dx_first_col", 0))
         # columns in front of `skip` are never computed: zero them so that the tensor handed to autograd is defined
-        dx = torch.empty(rows, cin0, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
-        if dx is not None and skip:
-            dx[:, :skip].zero_()
+        into = getattr(ctx, "dx_into", None)              # chain_pair_rows: add to the sibling chain's input gradient
+        flags = ctx.precision
+        if into is not None:
+            dx, flags = into, flags | _hip.CHAIN_ACCUMULATE_DX
+        else:
+            dx = torch.empty(rows, cin0, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+            if dx is not None and skip:
+                dx[:, :skip].zero_()
         sa = torch.empty(rows * maxc, dtype=torch.float32, device=dev)
         sb = torch.empty(rows * maxc, dtype=torch.float32, device=dev)
         seg_ptr, seg_keep = _hip.segments_arg(meta.get("seg_off") if ctx.nseg > 1 else None)
@@ -174,9 +179,43 @@ class _ChainFn(torch.autograd.Function):
         flops = 4 * rows * sum(int(a.cin) * int(a.cout) for a in arr)
         nbytes = 4 * rows * (cin0 + 5 * sum(int(a.cout) for a in arr))
         _hip.call("mlp_chain_bwd", lib.pn2_mlp_chain_bwd_f32, x.data_ptr(), x.stride(0), rows, arr, n, int(meta["pool_k"]),
-                  dout.data_ptr(), _hip.ptr(arg), _hip.ptr(dx), cin0, skip, sa.data_ptr(), sb.data_ptr(), seg_ptr, ctx.precision,
+                  dout.data_ptr(), _hip.ptr(arg), _hip.ptr(dx), cin0, skip, sa.data_ptr(), sb.data_ptr(), seg_ptr, flags,
                   ws.data_ptr(), ws.numel(), _hip.stream_ptr(), nbytes=nbytes, flops=flops)
         return (dx, None, *grads)
+
+
+class _Sub:
+    """Stands in for an autograd context when _ChainFn's forward / backward run as plain functions inside _ChainPairFn."""
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+
+class _ChainPairFn(torch.autograd.Function):
+    """Two chains on the SAME input rows as one autograd node: forward(x, meta_a, meta_b, n_a, *params_a, *params_b) ->
+    (out_a, out_b).  The backward runs both chains' backward passes and lets the second one ADD its input gradient to the
+    first one's (PN2_CHAIN_ACCUMULATE_DX) -- autograd would otherwise sum the two [rows, cin] tensors with a separate
+    kernel (65 us at 262144 x 128).  Same values: a + b either way."""
+
+    @staticmethod
+    def forward(ctx, x, meta_a, meta_b, n_a, *params):
+        a, b = _Sub(), _Sub()
+        out_a = _ChainFn.forward(a, x, meta_a, *params[:n_a])
+        out_b = _ChainFn.forward(b, x, meta_b, *params[n_a:])
+        ctx.subs = (a, b, n_a)
+        return out_a, out_b
+
+    @staticmethod
+    def backward(ctx, da, db):
+        a, b, n_a = ctx.subs
+        need = ctx.needs_input_grad
+        a.needs_input_grad = (need[0], False) + tuple(need[4:4 + n_a])
+        b.needs_input_grad = (need[0], False) + tuple(need[4 + n_a:])
+        ga = _ChainFn.backward(a, da)
+        b.dx_into = ga[0]
+        gb = _ChainFn.backward(b, db)
+        ctx.subs = None
+        return (ga[0], None, None, None) + tuple(ga[2:]) + tuple(gb[2:])
 
 
 class batched_counters:
@@ -199,16 +238,11 @@ class batched_counters:
                 torch._foreach_add_(ts, inc)
 
 
-def chain_rows(x, layers, pool_k=1, seg_off=None, dx_first_col=0):
-    """x [R, C_in] fp32 rows; layers: iterable of (conv, bn_or_None, relu: bool).
-    -> [R, C_out], or [R // pool_k, C_out] (max over each group of pool_k consecutive rows) when pool_k > 1.
-    seg_off: optional ascending row offsets [0, ..., R] of the mini-batches the rows are made of (whole-tree execution):
-    train-mode BatchNorm then works per segment, exactly as if the segments had been separate calls, and every layer's
-    running statistics / num_batches_tracked advance once per segment.
-    dx_first_col: the gradient w.r.t. x is only needed from this column on (the leading columns come back as zeros)."""
+def _chain_spec(layers, pool_k, seg_off, dx_first_col):
+    """(meta, params) of a chain call, or None for an empty chain; bumps num_batches_tracked."""
     layers = list(layers)
     if not layers:
-        return x
+        return None
     specs, params, training, bump = [], [], False, []
     for conv, bn, relu in layers:
         w = conv.weight.reshape(conv.out_channels, -1)
@@ -243,4 +277,28 @@ def chain_rows(x, layers, pool_k=1, seg_off=None, dx_first_col=0):
             batched_counters.active.pending += [(t, inc) for t in bump]
         else:
             torch._foreach_add_(bump, inc)
-    return _ChainFn.apply(x, meta, *params)
+    return meta, params
+
+
+def chain_rows(x, layers, pool_k=1, seg_off=None, dx_first_col=0):
+    """x [R, C_in] fp32 rows; layers: iterable of (conv, bn_or_None, relu: bool).
+    -> [R, C_out], or [R // pool_k, C_out] (max over each group of pool_k consecutive rows) when pool_k > 1.
+    seg_off: optional ascending row offsets [0, ..., R] of the mini-batches the rows are made of (whole-tree execution):
+    train-mode BatchNorm then works per segment, exactly as if the segments had been separate calls, and every layer's
+    running statistics / num_batches_tracked advance once per segment.
+    dx_first_col: the gradient w.r.t. x is only needed from this column on (the leading columns come back as zeros)."""
+    spec = _chain_spec(layers, pool_k, seg_off, dx_first_col)
+    if spec is None:
+        return x
+    return _ChainFn.apply(x, spec[0], *spec[1])
+
+
+def chain_pair_rows(x, layers_a, layers_b, seg_off=None):
+    """Two chains reading the same rows x [R, C_in] (the two prediction heads on the backbone features) ->
+    (out_a, out_b); one autograd node, the input gradient leaves as ONE tensor (see _ChainPairFn).  Falls back to two
+    chain_rows calls when either chain is empty or starts with a narrow layer."""
+    layers_a, layers_b = list(layers_a), list(layers_b)
+    if len(layers_a) < 2 or len(layers_b) < 2 or not x.is_cuda:
+        return chain_rows(x, layers_a, seg_off=seg_off), chain_rows(x, layers_b, seg_off=seg_off)
+    sa, sb = _chain_spec(layers_a, 1, seg_off, 0), _chain_spec(layers_b, 1, seg_off, 0)
+    return _ChainPairFn.apply(x, sa[0], sb[0], len(sa[1]), *sa[1], *sb[1])

@@ -27,7 +27,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _hip, ops
-from .mlp import batched_counters, chain_rows
+from .mlp import batched_counters, chain_pair_rows, chain_rows
 from .PointNet2.blocks import PointNetSetAbstractionMsg, _group_mlp_max
 
 MAX_ROWS_PER_PASS = 6_000_000       # level-0 rows (padded points) per pass: ~60 GB of activations at depth 5
@@ -172,8 +172,7 @@ def backbone_and_heads(model, layout, device):
                                        layout)
         feats = _fp_level(model.fp1, None, xyz[1], None, pts[1], layout, rc=rc)
         seg0 = layout.rows0.tolist()
-        sem = chain_rows(feats, model.semantic_linear._layers(), seg_off=seg0)
-        off = chain_rows(feats, model.offset_linear._layers(), seg_off=seg0)
+        sem, off = chain_pair_rows(feats, model.semantic_linear._layers(), model.offset_linear._layers(), seg_off=seg0)
     return sem, off
 
 

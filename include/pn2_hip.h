@@ -31,7 +31,7 @@ extern "C" {
 #define PN2_E_BADARG (-1)   /* null pointer / non-positive size / unsupported size */
 #define PN2_E_WORKSPACE (-2) /* workspace too small */
 
-#define PN2_ABI_VERSION 2
+#define PN2_ABI_VERSION 3
 
 /* Bits of the caller-owned sticky STATUS word (a device int32 the caller zeroes once and reads at a synchronisation
  * point it has anyway, e.g. the loss read-back; the Python mirror: ops.check_status()).  A kernel ORs a bit in when it
@@ -265,6 +265,11 @@ typedef struct pn2_segments {
  *                       its own, looser tolerance (tests/test_bf16_mode.py); small layers still run fp32. */
 #define PN2_PRECISION_F32 0
 #define PN2_PRECISION_BF16 1
+/* pn2_mlp_chain_bwd_f32 only, OR-ed into `precision`: ADD the input gradient to what `dx` holds instead of storing it
+ * (columns dx_first_col .. cin-1; the first layer must not be a narrow one).  Lets two chains that read the same input --
+ * the semantic and the offset head on the backbone features, PointNet2.py:86-87 -- leave one gradient tensor behind
+ * without a separate 3 x rows x cin x 4 byte add. */
+#define PN2_CHAIN_ACCUMULATE_DX 0x100
 
 size_t pn2_mlp_workspace_bytes(int rows, const pn2_mlp_layer *layers, int nlayers, int nseg);
 int pn2_mlp_chain_fwd_f32(const float *x, int64_t ldx, int rows, const pn2_mlp_layer *layers, int nlayers,
