@@ -217,7 +217,8 @@ struct GemmArgs {
     long long ldey;
     const float* ecoef;
     int erelu;
-    int accumulate;       // EPI_STORE: C += result (PN2_CHAIN_ACCUMULATE_DX)
+    int accumulate;       // EPI_STORE: C += result (PN2_CHAIN_ACCUMULATE_DX): the accumulators START from C -- the loads
+                          // travel with the first K-tile's instead of forming a read-modify-write chain in the epilogue
 };
 
 // TILE = 128: four waves own 64 x 64 each (2 x 2 MFMA accumulators); TILE = 64: 32 x 32 each (one accumulator),
@@ -250,10 +251,7 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& g, f32x16 (&a
                 const float val = acc[i][j][r] + bias;
                 acc[i][j][r] = val;
                 if (FULL || row < g.M) {
-                    if (cok) {
-                        float* c = C + (long long)row * g.ldc + col;
-                        *c = (EPI == EPI_STORE && g.accumulate) ? *c + val : val;
-                    }
+                    if (cok) C[(long long)row * g.ldc + col] = val;
                     sum += val;
                     ++cnt;
                 }
@@ -370,6 +368,19 @@ __global__ __launch_bounds__(NT * TEAMS, (TEAMS > 1 ? 1 : (EPI == EPI_STORE ? 2 
         for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    if (EPI == EPI_STORE && team == 0 && g.accumulate) {   // uniform per wavefront; the other teams add their partial tiles later
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int col = n0 + wn * WT + 32 * j + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * WT + 4 * half + 32 * i + (r & 3) + 8 * (r >> 2);
+                    if (row < g.M && col < g.N) acc[i][j][r] = g.C[(long long)row * g.ldc + col];
+                }
+            }
+    }
 
     Stager<A_T, A_KIND, TILE, VEC> sa;
     Stager<B_T, B_KIND, TILE, VEC> sb;

@@ -9,6 +9,8 @@ and hand their layers to ``chain_rows``; one C-ABI call runs the whole chain for
 """
 import ctypes
 
+import os
+
 import torch
 
 from . import _hip
@@ -298,7 +300,7 @@ def chain_pair_rows(x, layers_a, layers_b, seg_off=None):
     (out_a, out_b); one autograd node, the input gradient leaves as ONE tensor (see _ChainPairFn).  Falls back to two
     chain_rows calls when either chain is empty or starts with a narrow layer."""
     layers_a, layers_b = list(layers_a), list(layers_b)
-    if len(layers_a) < 2 or len(layers_b) < 2 or not x.is_cuda:
+    if len(layers_a) < 2 or len(layers_b) < 2 or not x.is_cuda or os.environ.get("PN2_NO_CHAIN_PAIR"):
         return chain_rows(x, layers_a, seg_off=seg_off), chain_rows(x, layers_b, seg_off=seg_off)
     sa, sb = _chain_spec(layers_a, 1, seg_off, 0), _chain_spec(layers_b, 1, seg_off, 0)
     return _ChainPairFn.apply(x, sa[0], sb[0], len(sa[1]), *sa[1], *sb[1])
