@@ -209,7 +209,7 @@ def main():
     model = PointNet2(depth=depth, loss_multiplier_semantic=0).to(dev).train()
     # parameters and gradients live in two flat, 16-byte-aligned buffers: one all-reduce and ONE fused AdamW launch per step
     grads = parallel.FlatGradAllReduce(model, flatten_params=True)
-    opt = torch.optim.AdamW([grads.flat_param], lr=0.01, weight_decay=1e-3, fused=True)   # train_PointNet2.py:250
+    opt = torch.optim.AdamW(grads.optimizer_params(), lr=0.01, weight_decay=1e-3, fused=True)   # train_PointNet2.py:250
     if rasterized:
         stream, labels, padded, n_rasters = make_raster_stream(args.points, seed=rank, device=dev)
     else:

@@ -1703,7 +1703,7 @@ extern "C" int pn2_fps_f32(const float* xyz, int64_t sb, int64_t sn, int64_t sc,
     const size_t need = pn2_fps_workspace_bytes(B, N, npoint);
     if (workspace_bytes < need) return PN2_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
-    PN2_HIP_CHECK(hipMemsetAsync(workspace, 0, need, s));
+    if (c.G > 1) PN2_HIP_CHECK(hipMemsetAsync(workspace, 0, need, s));   // one workgroup per cloud: no hand-off, no error word
     unsigned* err = (unsigned*)workspace;
     u64* gran = (u64*)((char*)workspace + kHdr);
     if (c.G > 1) {   // consecutive-block groups have no arrival phase to order an in-kernel fill: two memset nodes

@@ -11,7 +11,7 @@ dev = torch.device("cuda")
 torch.manual_seed(0)
 model = PointNet2(depth=4, loss_multiplier_semantic=0).to(dev).train()
 grads = parallel.FlatGradAllReduce(model, flatten_params=True)
-opt = torch.optim.AdamW([grads.flat_param], lr=0.01, weight_decay=1e-3, fused=True)
+opt = torch.optim.AdamW(grads.optimizer_params(), lr=0.01, weight_decay=1e-3, fused=True)
 batch = bench.make_batch(262144, seed=0, device=dev, trees=1)
 def step():
     grads.zero()
