@@ -995,6 +995,46 @@ __global__ __launch_bounds__(256) void slab_reduce_sliced_kernel(const float* __
     if (w == 0 && e < mn) out[e] += (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
+// All weight-gradient slab reductions of one chain call in ONE launch (a launch per layer is 5-8 us of mostly latency, 23
+// of them per backward pass): block b serves 64 elements of the task whose block range holds b, exactly like
+// slab_reduce_sliced_kernel (same summation order, so the result does not depend on how the work is batched).
+constexpr int SLAB_TASKS = 8;
+struct SlabTask {
+    const float* slab;
+    float* out;
+    long long mn;
+    int nsplit, first_block;
+};
+struct SlabTasks {
+    int n, blocks;
+    SlabTask t[SLAB_TASKS];
+};
+__global__ __launch_bounds__(256) void slab_reduce_multi_kernel(const SlabTasks T) {
+    __shared__ float part[4][64];
+    int k = 0;
+#pragma unroll
+    for (int i = 1; i < SLAB_TASKS; ++i)
+        if (i < T.n && (int)blockIdx.x >= T.t[i].first_block) k = i;
+    const float* __restrict__ slab = T.t[k].slab;
+    const long long mn = T.t[k].mn;
+    const int nsplit = T.t[k].nsplit;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long e = (long long)((int)blockIdx.x - T.t[k].first_block) * 64 + lane;
+    const int per = (nsplit + 3) / 4;
+    const int k0 = w * per, k1 = (k0 + per) < nsplit ? (k0 + per) : nsplit;
+    float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (e < mn) {
+        int q = k0;
+        for (; q + 8 <= k1; q += 8)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += slab[(long long)(q + u) * mn + e];
+        for (; q < k1; ++q) a[0] += slab[(long long)q * mn + e];
+    }
+    part[w][lane] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    __syncthreads();
+    if (w == 0 && e < mn) T.t[k].out[e] += (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+}
+
 // partial[blk][c] = sum over the block's rows of dz[r][c]  (bias of a layer WITHOUT BatchNorm, e.g. the last
 // conv of a head); summed in fixed order by colsum_finalize_kernel -> deterministic
 constexpr int CS_ROWS = 1024;
@@ -1278,6 +1318,19 @@ inline void launch_slab_reduce(const float* slab, int nsplit, long long mn, floa
                    mn, out);
 }
 
+inline void add_slab_task(SlabTasks& T, const float* slab, int nsplit, long long mn, float* out) {
+    SlabTask& t = T.t[T.n++];
+    t.slab = slab, t.out = out, t.mn = mn, t.nsplit = nsplit, t.first_block = T.blocks;
+    T.blocks += (int)((mn + 63) / 64);
+}
+inline void flush_slab_tasks(SlabTasks& T, hipStream_t s) {
+    if (!T.n) return;
+    double bytes = 0.0;
+    for (int i = 0; i < T.n; ++i) bytes += 4.0 * (T.t[i].nsplit + 2) * T.t[i].mn;
+    PN2_LAUNCH("slab_reduce", bytes, 0, slab_reduce_multi_kernel, dim3(T.blocks), dim3(256), s, T);
+    T.n = T.blocks = 0;
+}
+
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 // vector (16 B) staging is legal when rows start 16-byte aligned and the contiguous extent is a multiple of 4
@@ -1518,7 +1571,7 @@ int launch_bn_bwd_finalize(const float* partial, const FinScratch& fs, const Seg
 extern "C" size_t pn2_mlp_workspace_bytes(int rows, const pn2_mlp_layer* layers, int nlayers, int nseg) {
     if (rows <= 0 || !layers || nlayers <= 0) return 0;
     if (nseg < 1) nseg = 1;
-    size_t need = 0;
+    size_t need = 0, arena = 0;
     for (int i = 0; i < nlayers; ++i) {
         const size_t cin = layers[i].cin, cout = layers[i].cout;
         // per-row-chunk partials (forward stats, backward sums): chunks are >= 32 rows (+ 2 per segment boundary);
@@ -1531,12 +1584,24 @@ extern "C" size_t pn2_mlp_workspace_bytes(int rows, const pn2_mlp_layer* layers,
         const size_t nblk = (size_t)pn2::ceil_div(rows, NR_ROWS) + nseg;
         const size_t narrow = nblk * (2 * cin + cout * cin + cout) * sizeof(float);           // narrow_bwd partials
         size_t m = part > cs ? part : cs;
-        m = m > slab ? m : slab;
         m = m > narrow ? m : narrow;
         need = need > m ? need : m;
+        arena += align256(slab);   // the weight-gradient slabs of ALL layers stay until the chain's one reduction launch
     }
-    return slice_region_of(rows, layers, nlayers, nseg) + align256(need) + 256;
+    return slice_region_of(rows, layers, nlayers, nseg) + align256(need) + 256 + arena;
 }
+
+namespace {
+// start of the slab arena inside a chain workspace (behind the shared scratch region)
+size_t slab_arena_offset(int rows, const pn2_mlp_layer* layers, int nlayers, int nseg) {
+    size_t arena = 0;
+    for (int i = 0; i < nlayers; ++i) {
+        const WgradPlan wp = plan_wgrad(rows, layers[i].cout, layers[i].cin, nseg);
+        arena += align256((size_t)wp.nsplit * layers[i].cout * layers[i].cin * sizeof(float));
+    }
+    return pn2_mlp_workspace_bytes(rows, layers, nlayers, nseg) - arena;
+}
+}  // namespace
 
 extern "C" int pn2_mlp_chain_fwd_f32(const float* x, int64_t ldx, int rows, const pn2_mlp_layer* layers, int nlayers,
                                      int training, int pool_k, float* out, int32_t* pool_arg, const pn2_segments* segments,
@@ -1632,6 +1697,8 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
     hipStream_t s = (hipStream_t)stream;
     const FinScratch sp = fin_scratch(workspace, S.nseg, chain_cmax(layers, nlayers));
     float* ws = (float*)((char*)workspace + slice_region_of(rows, layers, nlayers, S.nseg));
+    char* arena = (char*)workspace + slab_arena_offset(rows, layers, nlayers, S.nseg);
+    SlabTasks tasks{};
     // dz of the last layer: upstream gradient, or the max-pool scatter of it
     const float* dz = dout;
     long long lddz = layers[nlayers - 1].cout;
@@ -1727,7 +1794,7 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
             g.M = L.cout;
             g.N = L.cin;
             g.K = rows;
-            g.C = ws;
+            g.C = (float*)arena;
             g.ldc = L.cin;
             g.k_per_split = wp.kps;
             int st, nsplit = 0;
@@ -1738,7 +1805,9 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
                 st = in.coef ? launch_gemm<false, TR_PLAIN, false, TR_BNRELU, EPI_SLAB>(g, S, wp.tile, s, &nsplit)
                              : launch_gemm<false, TR_PLAIN, false, TR_PLAIN, EPI_SLAB>(g, S, wp.tile, s, &nsplit);
             if (st) return st;
-            launch_slab_reduce((const float*)ws, nsplit, (long long)L.cout * L.cin, L.dweight, s);
+            if (tasks.n == SLAB_TASKS) flush_slab_tasks(tasks, s);
+            add_slab_task(tasks, (const float*)arena, nsplit, (long long)L.cout * L.cin, L.dweight);
+            arena += align256((size_t)wp.nsplit * L.cout * L.cin * sizeof(float));
             PN2_LAUNCH_CHECK();
         }
         // ---- dgrad: dX[rows][cin] = dY W; when the previous layer has a BatchNorm its backward column sums are
@@ -1777,5 +1846,7 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
             which ^= 1;
         }
     }
+    flush_slab_tasks(tasks, s);
+    PN2_LAUNCH_CHECK();
     return 0;
 }
