@@ -60,6 +60,7 @@ SIGNATURES = {
     "pn2_arch": (ctypes.c_char_p, []),
     "pn2_square_distance_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _int, _int, _int, _vp, _vp]),
     "pn2_fps_workspace_bytes": (_sz, [_int, _int, _int]),
+    "pn2_fps_order_offset": (_sz, [_int, _int, _int]),
     "pn2_fps_f32": (_int, [_vp, _i64, _i64, _i64, _int, _int, _int, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "pn2_ball_query_workspace_bytes": (_sz, [_int, _int, _int, _int]),
     "pn2_ball_query_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _int, _int, _int, _f32, _int, _vp, _vp,
@@ -69,7 +70,7 @@ SIGNATURES = {
     "pn2_group_grad_f32": (_int, [_vp, _vp, _int, _int, _int, _int, _int, _int, _vp, _vp]),
     "pn2_gather_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _int, _int, _int, _int, _vp, _vp, _vp]),
     "pn2_gather_grad_f32": (_int, [_vp, _vp, _int, _int, _int, _int, _vp, _vp]),
-    "pn2_three_nn_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _int, _int, _int, _vp, _vp, _vp, _vp]),
+    "pn2_three_nn_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _int, _int, _int, _vp, _vp, _vp, _vp, _vp]),
     "pn2_three_interpolate_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _int, _int, _int, _int, _vp, _i64, _i64, _vp, _vp]),
     "pn2_three_interpolate_grad_workspace_bytes": (_sz, [_int, _int, _int, _int]),
     "pn2_three_interpolate_grad_f32": (_int, [_vp, _i64, _i64, _vp, _vp, _int, _int, _int, _int, _vp, _vp, _sz, _vp]),

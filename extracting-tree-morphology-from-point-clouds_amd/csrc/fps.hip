@@ -1632,6 +1632,15 @@ extern "C" size_t pn2_fps_workspace_bytes(int B, int N, int npoint) {
     return kHdr + (c.G > 1 ? (size_t)B * npoint * 4 * c.G * sizeof(u64) : 0);
 }
 
+// Where pn2_fps_f32 leaves the cell order of the clouds it sampled (int32 [B][N], a permutation of every cloud's point
+// indices: neighbours in space are neighbours in the array) inside its workspace, or (size_t)-1 when this problem does not
+// take the ordered kernel.  Valid until the workspace is written again; other kernels may use it to schedule by locality
+// (pn2_three_nn_f32's `order`) -- only ever as a permutation, never for a result.
+extern "C" size_t pn2_fps_order_offset(int B, int N, int npoint) {
+    if (B <= 0 || N <= 0 || npoint <= 0 || !use_xcd_kernel(N) || !use_multi_pick(N, npoint) || !use_sorted(B, N)) return (size_t)-1;
+    return order_layout(xcd_plain_bytes(B, N, npoint), B, N).order;
+}
+
 extern "C" int pn2_fps_f32(const float* xyz, int64_t sb, int64_t sn, int64_t sc, int B, int N, int npoint,
                            const int64_t* start, int32_t* out_idx, float* out_xyz, void* workspace,
                            size_t workspace_bytes, int32_t* status, void* stream) {

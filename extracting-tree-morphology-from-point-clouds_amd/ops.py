@@ -75,6 +75,18 @@ def square_distance(src, dst):
     return out
 
 
+# The cell order the last ordered FPS call left in its workspace (include/pn2_hip.h: pn2_fps_order_offset), by the identity of
+# the cloud tensor it sampled.  three_nn schedules its dense points with it when it is handed the same tensor (set
+# abstraction level 1 and feature propagation level 1 both see the level-0 cloud).  Only ever a permutation: a stale entry
+# (another cloud at the same address) costs locality, never a result.  One entry: the view keeps a 3 MB workspace alive.
+_spatial_order = {}
+_NO_ORDER = ctypes.c_size_t(-1).value
+
+
+def _cloud_key(xyz):
+    return (xyz.data_ptr(), tuple(xyz.shape), tuple(xyz.stride()), xyz.device.index)
+
+
 def furthest_point_sample(xyz, npoint, start):
     """xyz [B,N,3] (any strides), start [B] int64 on the device -> (idx int32 [B,npoint], new_xyz [B,npoint,3])."""
     _hip.require_device(xyz, start)
@@ -91,6 +103,10 @@ def furthest_point_sample(xyz, npoint, start):
     _hip.call("farthest_point_sample", lib.pn2_fps_f32, xyz.data_ptr(), *_strides3(xyz), B, N, npoint, start.data_ptr(),
               idx.data_ptr(), new_xyz.data_ptr(), ws.data_ptr(), ws.numel(), status_word(xyz.device).data_ptr(),
               _hip.stream_ptr(), nbytes=B * (12 * N + 8 * npoint))
+    off = lib.pn2_fps_order_offset(B, N, npoint)
+    if off != _NO_ORDER and not os.environ.get("PN2_FPS_NO_SORT"):
+        _spatial_order.clear()
+        _spatial_order[_cloud_key(xyz)] = ws[off:off + 4 * B * N].view(torch.int32).view(B, N)
     if _DEBUG:
         check_status(xyz.device)
     return idx, new_xyz
@@ -124,8 +140,9 @@ def three_nn(xyz1, xyz2, want_dist=False):
     idx = torch.empty(B, N, 3, dtype=torch.int32, device=xyz1.device)
     w = torch.empty(B, N, 3, dtype=torch.float32, device=xyz1.device)
     dist = torch.empty(B, N, 3, dtype=torch.float32, device=xyz1.device) if want_dist else None
+    order = _spatial_order.get(_cloud_key(xyz1)) if not os.environ.get("PN2_TNN_NO_ORDER") else None
     _hip.call("three_nn", _hip.lib().pn2_three_nn_f32, xyz1.data_ptr(), *_strides3(xyz1), xyz2.data_ptr(),
-              *_strides3(xyz2), B, N, S, idx.data_ptr(), w.data_ptr(), _hip.ptr(dist), _hip.stream_ptr(),
+              *_strides3(xyz2), B, N, S, idx.data_ptr(), w.data_ptr(), _hip.ptr(dist), _hip.ptr(order), _hip.stream_ptr(),
               nbytes=B * (12 * N + 12 * S + N * 3 * (8 + 4)))
     return (idx, w, dist) if want_dist else (idx, w)
 

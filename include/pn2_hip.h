@@ -68,8 +68,14 @@ int pn2_square_distance_f32(const float *src, int64_t ab, int64_t an, int64_t ac
  *            identical indices): PN2_FPS_NO_XCD (consecutive-block groups, write-through hand-off), PN2_FPS_NO_MULTI
  *            (one sample per exchange), PN2_FPS_FORCE_FALLBACK (the XCD-local kernels with their placement-independent
  *            grouping).
+ *   [r2] Clouds of 8 k - 262 k points with >= 200 samples are first put into CELL ORDER (a counting sort of the points by
+ *            the 16^3 cells of the cloud's bounding box along the Morton curve, kept in the workspace) so that a wavefront
+ *            holds neighbours; pn2_fps_order_offset() tells where that permutation (int32 [B][N]) lies -- (size_t)-1 when
+ *            the problem does not take this path -- for callers that want to schedule other kernels by locality
+ *            (pn2_three_nn_f32's `order`).  PN2_FPS_NO_SORT keeps the index-order kernels.
  */
 size_t pn2_fps_workspace_bytes(int B, int N, int npoint);
+size_t pn2_fps_order_offset(int B, int N, int npoint);
 int pn2_fps_f32(const float *xyz, int64_t sb, int64_t sn, int64_t sc, int B, int N, int npoint,
                 const int64_t *start, int32_t *out_idx, float *out_xyz, void *workspace,
                 size_t workspace_bytes, int32_t *status, void *stream);
@@ -113,10 +119,13 @@ int pn2_gather_grad_f32(const float *dout, const int32_t *idx, int B, int N, int
  *   for every xyz1 point the 3 smallest square_distance(xyz1, xyz2) entries, ties -> lower index first;
  *   out_idx [B,N,3] int32, out_w [B,N,3] normalised inverse-distance weights, out_dist [B,N,3] or NULL.
  *   Requires S >= 3.
+ *   order   NULL, or int32 [B][N]: a permutation of every cloud's point indices (thread t of cloud b works on point
+ *           order[b][t]).  Results do not depend on it; a spatial order (pn2_fps_order_offset) lets a wavefront's 64 points
+ *           share their nearest samples, which is what the scan's early-out needs.
  */
 int pn2_three_nn_f32(const float *xyz1, int64_t ab, int64_t an, int64_t ac, const float *xyz2, int64_t bb,
                      int64_t bn, int64_t bc, int B, int N, int S, int32_t *out_idx, float *out_w,
-                     float *out_dist, void *stream);
+                     float *out_dist, const int32_t *order, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * masked point-wise loss            replaces the arithmetic of Modules/Loss.py:6-36 (point_wise_loss) under the masks

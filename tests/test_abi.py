@@ -63,6 +63,7 @@ def test_bad_arguments_are_rejected_on_the_host(cdll):
     box = up(64 + 1024 * 9 * 32 * 8)
     order = up(up(box + 8 * 4) + 2 * 4096 * 4)
     assert cdll.pn2_fps_workspace_bytes(1, 262144, 1024) == order + 262144 * 4
+    order1 = order
     box = up(64 + 8 * 1024 * 9 * 32 * 8)                                 # 8 clouds x 32 members x 4 points per lane
     order = up(up(box + 8 * 8 * 4) + 8 * 2 * 4096 * 4)
     assert cdll.pn2_fps_workspace_bytes(8, 65536, 1024) == order + 8 * 65536 * 4
@@ -72,7 +73,10 @@ def test_bad_arguments_are_rejected_on_the_host(cdll):
     assert cdll.pn2_fps_f32(null, i64(0), i64(0), i64(0), 1, 8, 4, null, null, null, null, ctypes.c_size_t(0), null,
                             null) == -1
     assert cdll.pn2_three_nn_f32(null, i64(0), i64(0), i64(0), null, i64(0), i64(0), i64(0), 1, 8, 3, null, null, null,
-                                 null) == -1
+                                 null, null) == -1
+    cdll.pn2_fps_order_offset.restype = ctypes.c_size_t
+    assert cdll.pn2_fps_order_offset(1, 1024, 16) == ctypes.c_size_t(-1).value      # no cell order for a single workgroup
+    assert cdll.pn2_fps_order_offset(1, 262144, 1024) == order1
 
 
 def test_cpu_tensors_fail_loudly():
