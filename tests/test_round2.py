@@ -587,3 +587,27 @@ def test_atomic_backward_run_to_run_bound(pn2):
         for o in outs:
             assert np.abs(o - want).max() <= 2e-4 * scale and np.abs(o - outs[0]).max() <= 2e-4 * scale
     ops.check_status()
+
+
+@pytest.mark.gpu
+def test_three_nn_in_cell_order_matches_oracle(pn2):
+    """three_nn handed the cloud an ordered FPS call just sampled walks it in that call's cell order (a permutation left in
+    the FPS workspace): neighbours, distances and weights must be what the index-order scan and the oracle give, ties
+    included (a fifth of the cloud is zero padding)."""
+    from pn2_amd import ops
+    O.build()
+    xyz = _cloud(2, 20000, seed=21, scale=0.7)
+    xyz[:, 16000:] = 0.0
+    dense = dev(xyz)
+    idx, new_xyz = ops.furthest_point_sample(dense, 256, dev(np.array([3, 4])))
+    ops.check_status()
+    order = ops._spatial_order.get(ops._cloud_key(dense))
+    assert order is not None and tuple(order.shape) == (2, 20000)
+    assert np.array_equal(np.sort(order.cpu().numpy(), axis=1), np.tile(np.arange(20000, dtype=np.int32), (2, 1)))
+    gi, gw, gd = ops.three_nn(dense, new_xyz, want_dist=True)
+    with env(PN2_TNN_NO_ORDER=1):
+        hi, hw, hd = ops.three_nn(dense, new_xyz, want_dist=True)
+    dist, want = O.three_nn(xyz, new_xyz.cpu().numpy())
+    assert np.array_equal(gi.cpu().numpy(), want) and np.array_equal(hi.cpu().numpy(), want)
+    assert torch.equal(gd, hd) and torch.equal(gw, hw)
+    assert np.array_equal(gd.cpu().numpy().view(np.uint32), dist.view(np.uint32))
