@@ -61,8 +61,13 @@ SIGNATURES = {
     "pn2_square_distance_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _int, _int, _int, _vp, _vp]),
     "pn2_fps_workspace_bytes": (_sz, [_int, _int, _int]),
     "pn2_fps_order_offset": (_sz, [_int, _int, _int]),
+    "pn2_fps_box_offset": (_sz, [_int, _int, _int]),
+    "pn2_fps_cellstart_offset": (_sz, [_int, _int, _int]),
+    "pn2_fps_sorted_xyz_offset": (_sz, [_int, _int, _int]),
     "pn2_fps_f32": (_int, [_vp, _i64, _i64, _i64, _int, _int, _int, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "pn2_ball_query_workspace_bytes": (_sz, [_int, _int, _int, _int]),
+    "pn2_ball_query_cells_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _int, _int, _int, _f32, _int, _vp, _vp, _vp,
+                                        _vp, _vp, _vp]),
     "pn2_ball_query_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _int, _int, _int, _f32, _int, _vp, _vp,
                                   _sz, _vp]),
     "pn2_group_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _vp, _int, _int, _int, _int, _int, _int,

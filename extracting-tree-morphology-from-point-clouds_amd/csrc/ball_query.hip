@@ -10,6 +10,7 @@
 //
 // Empty balls (only possible when the query is not a member of the cloud) take the row argmin, first minimum,
 // like torch.argmin (lines 113-122); short rows are padded with their first hit (lines 126-130).
+#include "pn2_cells.h"
 #include "pn2_common.h"
 #include <cstdio>
 #include <cstdlib>
@@ -248,6 +249,197 @@ Plan plan(int B, int N, int S) {
     return Plan{Q, (int)nseg, seg_len};
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Ball query over the cell structure an ordered FPS call left behind (fps.hip: the cloud's points counting-sorted into the
+// 16 x 16 x 16 cells of its bounding box).  One wavefront per query.
+//
+// The index-order walk stops as soon as nsample hits are found -- after N nsample / hits points, a microsecond for the
+// dense balls of these clouds -- but a ball with FEWER than nsample hits makes it scan the whole cloud (68 us at 262144
+// points), and a handful of such queries set the kernel's time.  Here a query first adds up the points of the cells its
+// ball can reach; if they are few (kCandMax) it tests exactly those, in cell order, and keeps the nsample SMALLEST hit
+// indices (what the index-order walk would have produced): hits go to an LDS list, at 4 nsample entries the list is cut
+// back to its nsample smallest (ranks by counting) and from then on only indices below the largest kept one are admitted.
+// Otherwise (a ball in a very dense region, or one whose rounding reach covers many cells) it walks in index order.
+//   reach: a point counts as inside when fl(-2 q.p + |q|^2 + |p|^2) <= r^2; that value differs from |q - p|^2 by at most
+//   err = 2^-20 (|q| + |p|)^2 (a generous bound on its seven roundings), so every hit has |q - p|_inf <= sqrt(r^2 + err)
+//   and lies in the cells of [q - R, q + R] per axis (cell numbers are monotone in the coordinate).
+constexpr int kList = 512, kMaxCells = 64, kCandMax = 8192;
+
+// leaves the min(keep, m) smallest entries of list[0..m) in ascending order in list[0..); returns how many.  m <= kList.
+__device__ int rank_select(int* list, int m, int keep, int* tmp, int lane) {
+    for (int e = lane; e < m; e += 64) {
+        const int v = list[e];
+        int r = 0;
+        for (int j = 0; j < m; ++j) r += list[j] < v ? 1 : 0;   // broadcast reads; entries are distinct point indices
+        tmp[e] = r;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    int vals[kList / 64], ranks[kList / 64];
+#pragma unroll
+    for (int k = 0; k < kList / 64; ++k) {
+        const int e = lane + 64 * k;
+        vals[k] = e < m ? list[e] : 0;
+        ranks[k] = e < m ? tmp[e] : keep;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < kList / 64; ++k)
+        if (ranks[k] < keep) list[ranks[k]] = vals[k];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    return m < keep ? m : keep;
+}
+
+__global__ __launch_bounds__(kBlock) void ball_query_cells_kernel(const float* __restrict__ xyz, int64_t sb, int64_t sn, int64_t sc,
+                                                                  const float* __restrict__ new_xyz, int64_t qb, int64_t qs,
+                                                                  int64_t qc, int B, int N, int S, float r2, int Keff,
+                                                                  const unsigned* __restrict__ box,
+                                                                  const int* __restrict__ cellstart,
+                                                                  const int* __restrict__ order,
+                                                                  const float* __restrict__ sorted_xyz,
+                                                                  int32_t* __restrict__ out_idx) {
+    __shared__ int s_list[kBlock / 64][kList];
+    __shared__ int s_tmp[kBlock / 64][kList];
+    __shared__ int s_cnt[kBlock / 64];
+    // one WORKGROUP per query: its four wavefronts share the cells' runs (the heaviest query sets the kernel's time, and a
+    // query is a chain of L2 round trips), keep a list each and merge them at the end
+    constexpr int NWV = kBlock / 64;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const long long w = (long long)blockIdx.x;
+    const int b = (int)(w / S), sq = (int)(w % S);
+    const Cloud c{xyz + (int64_t)b * sb, sn, sc};
+    const float* q = new_xyz + (int64_t)b * qb + (int64_t)sq * qs;
+    const float qx = q[0], qy = q[qc], qz = q[2 * qc];
+    const float qn = pn2::norm2(qx, qy, qz);
+    int32_t* row = out_idx + ((size_t)b * S + sq) * Keff;
+    int* list = s_list[wv];
+    int* tmp = s_tmp[wv];
+    const u64 lt = pn2::lanemask_lt();
+
+    const pn2::CellGrid cg = pn2::cell_grid(box + b * 8);
+    // largest |coordinate| of the cloud and of the query -> error bound of the expanded distance -> reach R
+    float mp = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) mp = fmaxf(mp, fmaxf(fabsf(cg.lo[a]), fabsf(pn2::ord_dec(box[b * 8 + a]))));
+    const float mq = fmaxf(fmaxf(fabsf(qx), fabsf(qy)), fabsf(qz));
+    const float norms = 1.7320509f * (mp + mq) * 1.0001f;                    // >= |q| + |p|
+    const float R = sqrtf(r2 + 9.5367432e-7f * norms * norms) * 1.0001f + 1e-30f;
+    int c0[3], c1[3];
+    const float qv[3] = {qx, qy, qz};
+    bool usable = R == R && R < 3.0e38f && Keff * NWV <= kList;
+    const int cut_at = 4 * Keff < kList - 64 ? 4 * Keff : kList - 64;   // the list never outgrows kList (64 appended at most)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        c0[a] = pn2::cell_axis(cg, a, qv[a] - R);
+        c1[a] = pn2::cell_axis(cg, a, qv[a] + R);
+        usable = usable && qv[a] == qv[a];
+    }
+    const int nx = c1[0] - c0[0] + 1, ny = c1[1] - c0[1] + 1, nz = c1[2] - c0[2] + 1;
+    const int ncell = nx * ny * nz;
+    usable = usable && ncell <= kMaxCells;
+    const int* cs = cellstart + (size_t)b * (pn2::kCells + 1);
+    // lane l < ncell: cell number l of the box -> its run of sorted positions
+    int p0 = 0, p1 = 0;
+    if (usable && lane < ncell) {
+        const int cx = c0[0] + lane % nx, cy = c0[1] + (lane / nx) % ny, cz = c0[2] + lane / (nx * ny);
+        const unsigned cell = pn2::spread3((unsigned)cx) | (pn2::spread3((unsigned)cy) << 1) | (pn2::spread3((unsigned)cz) << 2);
+        p0 = cs[cell];
+        p1 = cs[cell + 1];
+    }
+    int cand = p1 - p0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cand += __shfl_xor(cand, off, 64);
+    // Which way?  The cell search costs cand / 64 steps whatever the ball holds; the index-order walk costs
+    // N nsample / hits / 64 steps -- less only when the ball is really full.  hits ~ cand x (ball volume / volume of the
+    // reachable cells), a crude estimate (points sit on surfaces): walk only when it promises 8 nsample hits or more.
+    float cellvol = (float)ncell;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) cellvol = cg.scale[a] > 0.0f ? cellvol / cg.scale[a] : 0.0f;
+    const float rr = sqrtf(r2);
+    const float est = cellvol > 0.0f ? (float)cand * (4.18879f * rr * rr * rr) / cellvol : 0.0f;
+    int m = 0;   // entries in the list / hits so far (wave-uniform)
+    if (usable && (cand <= kCandMax || est < 8.0f * (float)Keff)) {
+        const int* ord = order + (size_t)b * N;
+        const float* sx = sorted_xyz + (size_t)b * 3 * N;
+        int limit = 0x7FFFFFFF;   // after the first cut: only indices below the largest kept one can still matter
+        // wavefront v takes blocks v, v + 4, ... of every cell's run, the next block's loads in flight while this one is tested
+        for (int ci = 0; ci < ncell; ++ci) {
+            const int a0 = __builtin_amdgcn_readlane(p0, ci) + 64 * wv, a1 = __builtin_amdgcn_readlane(p1, ci);
+            int nn = 0;
+            float xx = 0.f, yy = 0.f, zz = 0.f;
+            auto fetch = [&](int pos) {
+                const int at = pos + lane;
+                const size_t sa = at < a1 ? (size_t)at : (size_t)(a1 - 1);
+                nn = ord[sa];
+                xx = sx[sa], yy = sx[(size_t)N + sa], zz = sx[2 * (size_t)N + sa];
+            };
+            if (a0 < a1) fetch(a0);
+            for (int pos = a0; pos < a1; pos += 64 * NWV) {
+                const int cn = nn;
+                const float cx = xx, cy = yy, cz = zz;
+                if (pos + 64 * NWV < a1) fetch(pos + 64 * NWV);
+                const bool ok = pos + lane < a1;
+                const float d = pn2::sqdist(qx, qy, qz, qn, cx, cy, cz, pn2::norm2(cx, cy, cz));
+                const bool hit = ok && !(d > r2) && cn < limit;
+                const u64 hits = __ballot(hit);
+                if (hits) {   // wave-uniform
+                    if (hit) list[m + __popcll(hits & lt)] = cn;
+                    m += __popcll(hits);
+                    if (m >= cut_at) {   // keep the nsample smallest so far
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_wave_barrier();
+                        m = rank_select(list, m, Keff, tmp, lane);
+                        limit = list[Keff - 1];
+                    }
+                }
+            }
+        }
+        // every wavefront's nsample smallest, then the nsample smallest of those
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        m = rank_select(list, m, Keff, tmp, lane);
+        if (lane == 0) s_cnt[wv] = m;
+        __syncthreads();
+        if (wv != 0) return;
+        int total = s_cnt[0];
+        for (int v = 1; v < NWV; ++v) {
+            const int mv = s_cnt[v];
+            for (int k = lane; k < mv; k += 64) list[total + k] = s_list[v][k];
+            total += mv;
+        }
+        m = total;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        m = rank_select(list, m, Keff, tmp, lane);
+        for (int k = lane; k < m; k += 64) row[k] = list[k];
+        const int first = m > 0 ? list[0] : 0;
+        finish_row(c, N, row, m, first, Keff, qx, qy, qz, qn);
+        return;
+    }
+    // ---- index order, stop at nsample hits (the loads of the next block are in flight while this one is tested)
+    if (wv != 0) return;
+    int first = 0;
+    float nxv, nyv, nzv;
+    c.load(lane < N ? lane : 0, nxv, nyv, nzv);
+    for (int n0 = 0; n0 < N && m < Keff; n0 += 64) {
+        const int n = n0 + lane;
+        const bool ok = n < N;
+        const float x = nxv, y = nyv, z = nzv;
+        c.load(n + 64 < N ? n + 64 : 0, nxv, nyv, nzv);
+        const float d = pn2::sqdist(qx, qy, qz, qn, x, y, z, pn2::norm2(x, y, z));
+        const bool hit = ok && !(d > r2);
+        const u64 hits = __ballot(hit);
+        const int slot = m + __popcll(hits & lt);
+        if (hit && slot < Keff) row[slot] = n;
+        if (m == 0 && hits) first = n0 + (int)__builtin_ctzll(hits);
+        m += __popcll(hits);
+    }
+    if (m > Keff) m = Keff;
+    finish_row(c, N, row, m, first, Keff, qx, qy, qz, qn);
+}
+
 }  // namespace
 
 extern "C" size_t pn2_ball_query_workspace_bytes(int B, int N, int S, int nsample) {
@@ -290,6 +482,22 @@ extern "C" int pn2_ball_query_f32(const float* xyz, int64_t sb, int64_t sn, int6
                    s, xyz, sb, sn, sc, new_xyz, qb, qn, qc, B, N, S, Keff, out_idx, p.nseg, part_idx, part_cnt);
         PN2_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+extern "C" int pn2_ball_query_cells_f32(const float* xyz, int64_t sb, int64_t sn, int64_t sc, const float* new_xyz, int64_t qb,
+                                        int64_t qn, int64_t qc, int B, int N, int S, float r2, int nsample, const uint32_t* box,
+                                        const int32_t* cellstart, const int32_t* order, const float* sorted_xyz,
+                                        int32_t* out_idx, void* stream) {
+    if (!xyz || !new_xyz || !out_idx || !box || !cellstart || !order || !sorted_xyz || B <= 0 || N <= 0 || S <= 0 || nsample <= 0)
+        return PN2_E_BADARG;
+    const int Keff = nsample < N ? nsample : N;
+    const long long waves = (long long)B * S;
+    if (waves > 0x7FFFFFFFll) return PN2_E_BADARG;
+    PN2_LAUNCH("ball_query", (double)B * (12.0 * N + 12.0 * S + 8.0 * S * Keff), 8.0 * B * (double)S * N, ball_query_cells_kernel,
+               dim3((unsigned)waves), dim3(kBlock), (hipStream_t)stream, xyz, sb, sn, sc, new_xyz, qb, qn, qc, B, N, S, r2,
+               Keff, box, (const int*)cellstart, (const int*)order, sorted_xyz, out_idx);
+    PN2_LAUNCH_CHECK();
     return 0;
 }
 

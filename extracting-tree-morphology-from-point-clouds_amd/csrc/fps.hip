@@ -19,9 +19,17 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include "pn2_cells.h"
 #include "pn2_common.h"
 
 namespace {
+
+using pn2::cell_grid;
+using pn2::cell_of;
+using pn2::CellGrid;
+using pn2::kCells;
+using pn2::ord_dec;
+using pn2::ord_enc;
 
 using u64 = unsigned long long;
 using f2 = __attribute__((ext_vector_type(2))) float;
@@ -963,15 +971,6 @@ __global__ __launch_bounds__(kXT) void fps_multi_kernel(const float* __restrict_
 // The box test is made safe against the rounding of both sides: the update computes fl((dx*dx + dy*dy) + dz*dz) with
 // relative error < 2^-21.4 of the exact value and so does the box distance, hence the skip requires
 // box_distance * (1 - 2^-19) >= max d; non-finite values fail the comparison and are treated as "touched".
-constexpr int kCellBits = 4;                    // per axis: 16 x 16 x 16 cells of the cloud's bounding box
-constexpr int kCells = 1 << (3 * kCellBits);
-
-__device__ __forceinline__ unsigned ord_enc(float f) {   // order-preserving float -> u32
-    const unsigned u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float ord_dec(unsigned e) { return __uint_as_float((e & 0x80000000u) ? (e & 0x7FFFFFFFu) : ~e); }
-
 // The ordering kernels: workgroups of kOT threads, kOP points per thread (loads of a thread are independent: all in flight).
 constexpr int kOT = 1024, kOP = 8;
 
@@ -1010,35 +1009,6 @@ __global__ __launch_bounds__(kOT) void fps_box_kernel(const float* __restrict__ 
     }
 }
 
-__device__ __forceinline__ unsigned spread3(unsigned v) {   // bit i -> bit 3 i (good for 8 bits)
-    v = (v | (v << 8)) & 0x0000F00Fu;
-    v = (v | (v << 4)) & 0x000C30C3u;
-    v = (v | (v << 2)) & 0x00249249u;
-    return v;
-}
-
-// Morton number of the cell of a point: every axis of the cloud's box is cut into 16 (non-finite values land in cell 0 / 15).
-struct CellGrid {
-    float lo[3], scale[3];
-};
-__device__ __forceinline__ CellGrid cell_grid(const unsigned* box) {
-    CellGrid c;
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        c.lo[a] = ord_dec(~box[3 + a]);
-        const float ext = ord_dec(box[a]) - c.lo[a];
-        c.scale[a] = ext > 0.0f ? (float)(1 << kCellBits) / ext : 0.0f;
-    }
-    return c;
-}
-__device__ __forceinline__ unsigned cell_of(const CellGrid& c, float x, float y, float z) {
-    const float top = (float)((1 << kCellBits) - 1);
-    const unsigned cx = (unsigned)fminf(fmaxf((x - c.lo[0]) * c.scale[0], 0.0f), top);
-    const unsigned cy = (unsigned)fminf(fmaxf((y - c.lo[1]) * c.scale[1], 0.0f), top);
-    const unsigned cz = (unsigned)fminf(fmaxf((z - c.lo[2]) * c.scale[2], 0.0f), top);
-    return spread3(cx) | (spread3(cy) << 1) | (spread3(cz) << 2);
-}
-
 // total[b][cell] = points of cloud b in the cell (LDS histogram per workgroup, one global add per non-empty cell)
 __global__ __launch_bounds__(kOT) void fps_hist_kernel(const float* __restrict__ xyz, int64_t sb, int64_t sn, int64_t sc, int N,
                                                        const unsigned* __restrict__ box, unsigned* __restrict__ total) {
@@ -1067,7 +1037,8 @@ __global__ __launch_bounds__(kOT) void fps_hist_kernel(const float* __restrict__
 // never a result.
 __global__ __launch_bounds__(kOT) void fps_scatter_kernel(const float* __restrict__ xyz, int64_t sb, int64_t sn, int64_t sc, int N,
                                                           const unsigned* __restrict__ box, const unsigned* __restrict__ total,
-                                                          unsigned* __restrict__ cursor, unsigned* __restrict__ order) {
+                                                          unsigned* __restrict__ cursor, unsigned* __restrict__ order,
+                                                          unsigned* __restrict__ cellstart, float* __restrict__ sorted_xyz) {
     __shared__ unsigned base[kCells];   // first position of the cell; after the reservation: first position of this workgroup's run
     __shared__ unsigned h[kCells];
     __shared__ unsigned part[kOT];
@@ -1092,18 +1063,23 @@ __global__ __launch_bounds__(kOT) void fps_scatter_kernel(const float* __restric
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
         base[t * PER + k] = run;
+        if (blockIdx.x == 0) cellstart[(size_t)b * (kCells + 1) + t * PER + k] = run;   // kept for other kernels (ball query)
         run += v[k];
     }
+    if (blockIdx.x == 0 && t == kOT - 1) cellstart[(size_t)b * (kCells + 1) + kCells] = run;
     const CellGrid cg = cell_grid(box + b * 8);
     const float* p = xyz + (int64_t)b * sb;
     unsigned cell[kOP], arrival[kOP];
+    float px[kOP], py[kOP], pz[kOP];
 #pragma unroll
     for (int k = 0; k < kOP; ++k) {
         const int n = (blockIdx.x * kOP + k) * kOT + t;
         cell[k] = 0, arrival[k] = 0;
+        px[k] = py[k] = pz[k] = 0.0f;
         if (n < N) {
             const float* q = p + (int64_t)n * sn;
-            cell[k] = cell_of(cg, q[0], q[sc], q[2 * sc]);
+            px[k] = q[0], py[k] = q[sc], pz[k] = q[2 * sc];
+            cell[k] = cell_of(cg, px[k], py[k], pz[k]);
             arrival[k] = atomicAdd(&h[cell[k]], 1u);
         }
     }
@@ -1114,10 +1090,18 @@ __global__ __launch_bounds__(kOT) void fps_scatter_kernel(const float* __restric
         if (h[c]) base[c] += atomicAdd(cursor + (size_t)b * kCells + c, h[c]);
     }
     __syncthreads();
+    // the permutation and the coordinates in cell order (three planes per cloud: coalesced reads for whoever walks cells)
+    float* sx = sorted_xyz + (size_t)b * 3 * N;
 #pragma unroll
     for (int k = 0; k < kOP; ++k) {
         const int n = (blockIdx.x * kOP + k) * kOT + t;
-        if (n < N) order[(size_t)b * N + base[cell[k]] + arrival[k]] = (unsigned)n;
+        if (n < N) {
+            const size_t pos = base[cell[k]] + arrival[k];
+            order[(size_t)b * N + pos] = (unsigned)n;
+            sx[pos] = px[k];
+            sx[(size_t)N + pos] = py[k];
+            sx[2 * (size_t)N + pos] = pz[k];
+        }
     }
 }
 
@@ -1591,7 +1575,7 @@ Knobs knobs(int32_t* status) {
 
 // Workspace of the spatially ordered path behind the header and the granules: [boxes][cell totals][cell cursors][order].
 struct OrderLayout {
-    size_t box, total, cursor, order, end;
+    size_t box, total, cursor, cellstart, order, sorted_xyz, end;
 };
 inline OrderLayout order_layout(size_t head, int B, int N) {
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
@@ -1599,8 +1583,10 @@ inline OrderLayout order_layout(size_t head, int B, int N) {
     L.box = up(head);
     L.total = up(L.box + (size_t)B * 8 * sizeof(unsigned));
     L.cursor = L.total + (size_t)B * kCells * sizeof(unsigned);
-    L.order = up(L.cursor + (size_t)B * kCells * sizeof(unsigned));
-    L.end = L.order + (size_t)B * N * sizeof(unsigned);
+    L.cellstart = up(L.cursor + (size_t)B * kCells * sizeof(unsigned));
+    L.order = up(L.cellstart + (size_t)B * (kCells + 1) * sizeof(unsigned));
+    L.sorted_xyz = up(L.order + (size_t)B * N * sizeof(unsigned));
+    L.end = L.sorted_xyz + (size_t)B * 3 * N * sizeof(float);
     return L;
 }
 inline bool use_sorted(int B, int N) {
@@ -1640,6 +1626,21 @@ extern "C" size_t pn2_fps_order_offset(int B, int N, int npoint) {
     if (B <= 0 || N <= 0 || npoint <= 0 || !use_xcd_kernel(N) || !use_multi_pick(N, npoint) || !use_sorted(B, N)) return (size_t)-1;
     return order_layout(xcd_plain_bytes(B, N, npoint), B, N).order;
 }
+// ... and the cell structure behind it: the cloud's box (uint32 [B][8], csrc/pn2_cells.h) and the first sorted position of
+// every cell (int32 [B][4097], Morton-numbered 16 x 16 x 16 cells, last entry N).
+extern "C" size_t pn2_fps_box_offset(int B, int N, int npoint) {
+    if (pn2_fps_order_offset(B, N, npoint) == (size_t)-1) return (size_t)-1;
+    return order_layout(xcd_plain_bytes(B, N, npoint), B, N).box;
+}
+extern "C" size_t pn2_fps_cellstart_offset(int B, int N, int npoint) {
+    if (pn2_fps_order_offset(B, N, npoint) == (size_t)-1) return (size_t)-1;
+    return order_layout(xcd_plain_bytes(B, N, npoint), B, N).cellstart;
+}
+// ... and the coordinates in cell order: float [B][3][N] (x, y, z planes; entry p of a plane belongs to point order[p])
+extern "C" size_t pn2_fps_sorted_xyz_offset(int B, int N, int npoint) {
+    if (pn2_fps_order_offset(B, N, npoint) == (size_t)-1) return (size_t)-1;
+    return order_layout(xcd_plain_bytes(B, N, npoint), B, N).sorted_xyz;
+}
 
 extern "C" int pn2_fps_f32(const float* xyz, int64_t sb, int64_t sn, int64_t sc, int B, int N, int npoint,
                            const int64_t* start, int32_t* out_idx, float* out_xyz, void* workspace,
@@ -1656,7 +1657,7 @@ extern "C" int pn2_fps_f32(const float* xyz, int64_t sb, int64_t sn, int64_t sc,
             const int ppt = multi_ppt(N), G = multi_group_size(N);
             const OrderLayout L = order_layout(xcd_plain_bytes(B, N, npoint), B, N);
             char* w = (char*)workspace;
-            PN2_HIP_CHECK(hipMemsetAsync(workspace, 0, L.order, s));   // header, granules, boxes, cell counters
+            PN2_HIP_CHECK(hipMemsetAsync(workspace, 0, L.cellstart, s));   // header, granules, boxes, cell counters
             unsigned* box = (unsigned*)(w + L.box);
             unsigned* total = (unsigned*)(w + L.total);
             unsigned* cursor = (unsigned*)(w + L.cursor);
@@ -1666,7 +1667,8 @@ extern "C" int pn2_fps_f32(const float* xyz, int64_t sb, int64_t sn, int64_t sc,
                 const dim3 grid(pn2::ceil_div(N, kOT * kOP), B);
                 hipLaunchKernelGGL(fps_box_kernel, grid, dim3(kOT), 0, s, xyz, sb, sn, sc, N, box);
                 hipLaunchKernelGGL(fps_hist_kernel, grid, dim3(kOT), 0, s, xyz, sb, sn, sc, N, box, total);
-                hipLaunchKernelGGL(fps_scatter_kernel, grid, dim3(kOT), 0, s, xyz, sb, sn, sc, N, box, total, cursor, order);
+                hipLaunchKernelGGL(fps_scatter_kernel, grid, dim3(kOT), 0, s, xyz, sb, sn, sc, N, box, total, cursor, order,
+                                   (unsigned*)(w + L.cellstart), (float*)(w + L.sorted_xyz));
             }
             const double fb = (double)B * (12.0 * N + 8.0 * npoint);
             const int per = sorted_per(N);

@@ -80,6 +80,7 @@ def square_distance(src, dst):
 # abstraction level 1 and feature propagation level 1 both see the level-0 cloud).  Only ever a permutation: a stale entry
 # (another cloud at the same address) costs locality, never a result.  One entry: the view keeps a 3 MB workspace alive.
 _spatial_order = {}
+_cell_index = {}          # same key -> (box, first sorted position of every cell): ball_query searches by cell with them
 _NO_ORDER = ctypes.c_size_t(-1).value
 
 
@@ -107,6 +108,11 @@ def furthest_point_sample(xyz, npoint, start):
     if off != _NO_ORDER and not os.environ.get("PN2_FPS_NO_SORT"):
         _spatial_order.clear()
         _spatial_order[_cloud_key(xyz)] = ws[off:off + 4 * B * N].view(torch.int32).view(B, N)
+        boff, coff = lib.pn2_fps_box_offset(B, N, npoint), lib.pn2_fps_cellstart_offset(B, N, npoint)
+        _cell_index.clear()
+        xoff = lib.pn2_fps_sorted_xyz_offset(B, N, npoint)
+        _cell_index[_cloud_key(xyz)] = (ws[boff:boff + 32 * B].view(torch.int32), ws[coff:coff + 4 * 4097 * B].view(torch.int32),
+                                        ws[xoff:xoff + 12 * B * N].view(torch.float32))
     if _DEBUG:
         check_status(xyz.device)
     return idx, new_xyz
@@ -121,8 +127,17 @@ def ball_query(radius, nsample, xyz, new_xyz):
     keff = min(int(nsample), N)
     lib = _hip.lib()
     out = torch.empty(B, S, keff, dtype=torch.int32, device=xyz.device)
-    ws = _workspace(lib.pn2_ball_query_workspace_bytes(B, N, S, int(nsample)), xyz.device)
     r2 = ctypes.c_float(float(radius) ** 2).value  # float32(double(radius)**2), pointnet2_utils.py:107
+    key = _cloud_key(xyz)
+    if key in _cell_index and key in _spatial_order and not os.environ.get("PN2_BQ_NO_CELLS"):
+        # the cloud was just sampled by an ordered FPS call: sparse balls are searched in the cells it left behind
+        box, cellstart, sorted_xyz = _cell_index[key]
+        _hip.call("query_ball_point", lib.pn2_ball_query_cells_f32, xyz.data_ptr(), *_strides3(xyz), new_xyz.data_ptr(),
+                  *_strides3(new_xyz), B, N, S, r2, int(nsample), box.data_ptr(), cellstart.data_ptr(),
+                  _spatial_order[key].data_ptr(), sorted_xyz.data_ptr(), out.data_ptr(), _hip.stream_ptr(),
+                  nbytes=B * (12 * N + 12 * S + 8 * S * keff))
+        return out
+    ws = _workspace(lib.pn2_ball_query_workspace_bytes(B, N, S, int(nsample)), xyz.device)
     _hip.call("query_ball_point", lib.pn2_ball_query_f32, xyz.data_ptr(), *_strides3(xyz), new_xyz.data_ptr(),
               *_strides3(new_xyz), B, N, S, r2, int(nsample), out.data_ptr(), ws.data_ptr(), ws.numel(),
               _hip.stream_ptr(), nbytes=B * (12 * N + 12 * S + 8 * S * keff))

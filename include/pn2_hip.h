@@ -76,6 +76,9 @@ int pn2_square_distance_f32(const float *src, int64_t ab, int64_t an, int64_t ac
  */
 size_t pn2_fps_workspace_bytes(int B, int N, int npoint);
 size_t pn2_fps_order_offset(int B, int N, int npoint);
+size_t pn2_fps_box_offset(int B, int N, int npoint);       /* uint32 [B][8]: the clouds' boxes (order-preserving encodings) */
+size_t pn2_fps_cellstart_offset(int B, int N, int npoint); /* int32 [B][4097]: first sorted position of every cell, then N */
+size_t pn2_fps_sorted_xyz_offset(int B, int N, int npoint); /* float [B][3][N]: x, y, z planes in cell order */
 int pn2_fps_f32(const float *xyz, int64_t sb, int64_t sn, int64_t sc, int B, int N, int npoint,
                 const int64_t *start, int32_t *out_idx, float *out_xyz, void *workspace,
                 size_t workspace_bytes, int32_t *status, void *stream);
@@ -91,6 +94,16 @@ size_t pn2_ball_query_workspace_bytes(int B, int N, int S, int nsample);
 int pn2_ball_query_f32(const float *xyz, int64_t sb, int64_t sn, int64_t sc, const float *new_xyz,
                        int64_t qb, int64_t qn, int64_t qc, int B, int N, int S, float r2, int nsample,
                        int32_t *out_idx, void *workspace, size_t workspace_bytes, void *stream);
+/* The same rows from the cell structure an ordered pn2_fps_f32 call on the SAME cloud left in its workspace (box,
+ * cellstart, order, sorted_xyz: see pn2_fps_*_offset).  One wavefront per query.  Unless the ball promises to be full
+ * (estimated hits >= 8 nsample among more than 8192 candidates) its reachable cells (rounding of the reference's expanded
+ * distance included) are searched: every candidate is tested with the exact expression, the nsample smallest hit indices
+ * are kept (ascending).  Full balls are walked in index order until nsample hits.  What this buys: the index-order walk of a ball with FEWER than nsample hits is a scan of the whole
+ * cloud (68 us at 262144 points), and those queries set the kernel's time. */
+int pn2_ball_query_cells_f32(const float *xyz, int64_t sb, int64_t sn, int64_t sc, const float *new_xyz, int64_t qb,
+                             int64_t qn, int64_t qc, int B, int N, int S, float r2, int nsample, const uint32_t *box,
+                             const int32_t *cellstart, const int32_t *order, const float *sorted_xyz, int32_t *out_idx,
+                             void *stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * group_points (+ centring + concat)   replaces index_points x2 and lines 156-161 of sample_and_group

@@ -57,16 +57,16 @@ def test_bad_arguments_are_rejected_on_the_host(cdll):
     assert cdll.pn2_fps_workspace_bytes(1, 2_000_000, 4) == 0          # beyond 64 members x 16384 points
     assert cdll.pn2_fps_workspace_bytes(1, 1024, 16) == 16              # single workgroup: error word only
     # XCD-local ordered multi-pick rounds, 32 members x 16 points per lane: header + 9 granules {2 x (key, x, y, z), bound} per
-    # member and round (at most npoint rounds), then -- each 256-byte aligned -- the cloud's box, 2 x 4096 cell counters and
-    # the cell order of the points
+    # member and round (at most npoint rounds), then -- each 256-byte aligned -- the cloud's box, 2 x 4096 cell counters, the
+    # 4097 cell starts and the cell order of the points
     up = lambda v: (v + 255) // 256 * 256
     box = up(64 + 1024 * 9 * 32 * 8)
-    order = up(up(box + 8 * 4) + 2 * 4096 * 4)
-    assert cdll.pn2_fps_workspace_bytes(1, 262144, 1024) == order + 262144 * 4
+    order = up(up(up(box + 8 * 4) + 2 * 4096 * 4) + 4097 * 4)
+    assert cdll.pn2_fps_workspace_bytes(1, 262144, 1024) == up(order + 262144 * 4) + 3 * 262144 * 4     # + coordinates in cell order
     order1 = order
     box = up(64 + 8 * 1024 * 9 * 32 * 8)                                 # 8 clouds x 32 members x 4 points per lane
-    order = up(up(box + 8 * 8 * 4) + 8 * 2 * 4096 * 4)
-    assert cdll.pn2_fps_workspace_bytes(8, 65536, 1024) == order + 8 * 65536 * 4
+    order = up(up(up(box + 8 * 8 * 4) + 8 * 2 * 4096 * 4) + 8 * 4097 * 4)
+    assert cdll.pn2_fps_workspace_bytes(8, 65536, 1024) == up(order + 8 * 65536 * 4) + 3 * 8 * 65536 * 4
     null = ctypes.c_void_p(None)
     i64 = ctypes.c_int64
     # null pointers -> PN2_E_BADARG before any HIP call

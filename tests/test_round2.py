@@ -611,3 +611,38 @@ def test_three_nn_in_cell_order_matches_oracle(pn2):
     assert np.array_equal(gi.cpu().numpy(), want) and np.array_equal(hi.cpu().numpy(), want)
     assert torch.equal(gd, hd) and torch.equal(gw, hw)
     assert np.array_equal(gd.cpu().numpy().view(np.uint32), dist.view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["members", "strangers", "dense", "far_origin", "tiny_radius", "big_k", "huge_k"])
+def test_ball_query_by_cells_matches_oracle(pn2, case):
+    """query_ball_point on a cloud an ordered FPS call just sampled searches the cells that call left in its workspace.
+    Same rows as the oracle's index-order scan: queries that are cloud members and queries that are not (empty balls take
+    the arg-min), balls with far more hits than nsample (list cuts + index limit), coordinates far from the origin (the
+    reach of the expanded distance's rounding covers many cells: index-order walk), a radius below the point spacing,
+    nsample > 64 and nsample too large for the list."""
+    from pn2_amd import ops
+    O.build()
+    B, N, S, r, K = 2, 30000, 300, 0.15, 32
+    xyz = _cloud(B, N, seed=31, scale=1.0)
+    if case == "dense":
+        xyz = _cloud(B, N, seed=32, scale=0.05)              # thousands of points inside every ball
+    elif case == "far_origin":
+        xyz = _cloud(B, N, seed=33, scale=1.0, shift=(5000.0, -7000.0, 300.0))
+    elif case == "tiny_radius":
+        r = 0.004
+    elif case == "big_k":
+        K, r = 100, 0.3
+    elif case == "huge_k":
+        K, r = 300, 0.5
+    dense = dev(xyz)
+    idx, new_xyz = ops.furthest_point_sample(dense, S, dev(np.array([1, 2])))
+    ops.check_status()
+    assert ops._cloud_key(dense) in ops._cell_index
+    q = new_xyz if case != "strangers" else new_xyz + 0.37
+    want = O.query_ball_point(r, K, xyz, q.cpu().numpy())
+    got = ops.ball_query(r, K, dense, q)
+    with env(PN2_BQ_NO_CELLS=1):
+        scan = ops.ball_query(r, K, dense, q)
+    assert np.array_equal(scan.cpu().numpy(), want)
+    assert np.array_equal(got.cpu().numpy(), want)
