@@ -84,6 +84,8 @@ SIGNATURES = {
                                 ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _int]),
     "pn2_mlp_workspace_bytes": (_sz, [_int, _lp, _int, _int]),
     "pn2_mlp_chain_fwd_f32": (_int, [_vp, _i64, _int, _lp, _int, _int, _int, _vp, _vp, _sp, _int, _vp, _sz, _vp]),
+    "pn2_mlp_flush_wgrad": (_int, [_vp]),
+    "pn2_mlp_drop_wgrad": (_int, []),
     "pn2_mlp_chain_bwd_f32": (_int, [_vp, _i64, _int, _lp, _int, _int, _vp, _vp, _vp, _i64, _int, _vp, _vp, _sp, _int, _vp, _sz, _vp]),
     "pn2_cylinder_project_f32": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _vp]),
     "pn2_raster_ranges_f32": (_int, [_vp, _i64, _int, _vp, _int, _int, _int, _vp, _vp, _vp]),
@@ -104,6 +106,7 @@ SIGNATURES = {
 _lib = None
 ABI_VERSION = 3                      # PN2_ABI_VERSION of include/pn2_hip.h
 CHAIN_ACCUMULATE_DX = 0x100          # PN2_CHAIN_ACCUMULATE_DX
+CHAIN_DEFER_WGRAD = 0x200            # PN2_CHAIN_DEFER_WGRAD
 STATUS_FPS_HANDOFF, STATUS_FPS_ARRIVAL, STATUS_BAD_INDEX = 1, 2, 4   # PN2_STATUS_* bits
 
 

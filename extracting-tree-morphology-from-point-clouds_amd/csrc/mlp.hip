@@ -22,6 +22,9 @@
 //                                                                    fixed-order slab sum -> deterministic)
 #include <stdlib.h>
 
+#include <mutex>
+#include <vector>
+
 #include "pn2_common.h"
 #include <cstdlib>
 
@@ -998,7 +1001,7 @@ __global__ __launch_bounds__(256) void slab_reduce_sliced_kernel(const float* __
 // All weight-gradient slab reductions of one chain call in ONE launch (a launch per layer is 5-8 us of mostly latency, 23
 // of them per backward pass): block b serves 64 elements of the task whose block range holds b, exactly like
 // slab_reduce_sliced_kernel (same summation order, so the result does not depend on how the work is batched).
-constexpr int SLAB_TASKS = 8;
+constexpr int SLAB_TASKS = 32;
 struct SlabTask {
     const float* slab;
     float* out;
@@ -1323,6 +1326,11 @@ inline void add_slab_task(SlabTasks& T, const float* slab, int nsplit, long long
     t.slab = slab, t.out = out, t.mn = mn, t.nsplit = nsplit, t.first_block = T.blocks;
     T.blocks += (int)((mn + 63) / 64);
 }
+// Deferred reductions (PN2_CHAIN_DEFER_WGRAD): the tasks of every chain backward of a pass, launched together by
+// pn2_mlp_flush_wgrad.  Process-wide (the autograd engine calls the chains from its own threads).
+std::mutex g_pending_mutex;
+std::vector<SlabTask> g_pending;
+
 inline void flush_slab_tasks(SlabTasks& T, hipStream_t s) {
     if (!T.n) return;
     double bytes = 0.0;
@@ -1687,7 +1695,8 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
     if (!x || !layers || nlayers <= 0 || rows <= 0 || !dout || !scratch_a || !scratch_b) return PN2_E_BADARG;
     if (dx_first_col < 0 || dx_first_col >= layers[0].cin) return PN2_E_BADARG;
     const int accumulate_dx = (precision & PN2_CHAIN_ACCUMULATE_DX) ? 1 : 0;
-    precision &= ~PN2_CHAIN_ACCUMULATE_DX;
+    const bool defer_wgrad = (precision & PN2_CHAIN_DEFER_WGRAD) != 0;
+    precision &= ~(PN2_CHAIN_ACCUMULATE_DX | PN2_CHAIN_DEFER_WGRAD);
     if (precision != PN2_PRECISION_F32 && precision != PN2_PRECISION_BF16) return PN2_E_BADARG;
     if (accumulate_dx && !dx) return PN2_E_BADARG;
     t_precision = precision;
@@ -1805,7 +1814,8 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
                 st = in.coef ? launch_gemm<false, TR_PLAIN, false, TR_BNRELU, EPI_SLAB>(g, S, wp.tile, s, &nsplit)
                              : launch_gemm<false, TR_PLAIN, false, TR_PLAIN, EPI_SLAB>(g, S, wp.tile, s, &nsplit);
             if (st) return st;
-            if (tasks.n == SLAB_TASKS) flush_slab_tasks(tasks, s);
+            if (tasks.n == SLAB_TASKS && !defer_wgrad) flush_slab_tasks(tasks, s);
+            if (tasks.n == SLAB_TASKS) return PN2_E_BADARG;   // more layers than a task table holds
             add_slab_task(tasks, (const float*)arena, nsplit, (long long)L.cout * L.cin, L.dweight);
             arena += align256((size_t)wp.nsplit * L.cout * L.cin * sizeof(float));
             PN2_LAUNCH_CHECK();
@@ -1846,7 +1856,38 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
             which ^= 1;
         }
     }
-    flush_slab_tasks(tasks, s);
+    if (defer_wgrad) {
+        std::lock_guard<std::mutex> lock(g_pending_mutex);
+        for (int i = 0; i < tasks.n; ++i) g_pending.push_back(tasks.t[i]);
+    } else {
+        flush_slab_tasks(tasks, s);
+    }
     PN2_LAUNCH_CHECK();
     return 0;
+}
+
+// The weight-gradient reductions of every pn2_mlp_chain_bwd_f32 call made with PN2_CHAIN_DEFER_WGRAD since the last flush,
+// in as few launches as the task table allows (32 tasks each).  The workspaces of those calls must still be alive.
+extern "C" int pn2_mlp_flush_wgrad(void* stream) {
+    std::vector<SlabTask> todo;
+    {
+        std::lock_guard<std::mutex> lock(g_pending_mutex);
+        todo.swap(g_pending);
+    }
+    hipStream_t s = (hipStream_t)stream;
+    SlabTasks T{};
+    for (const SlabTask& t : todo) {
+        if (T.n == SLAB_TASKS) flush_slab_tasks(T, s);
+        add_slab_task(T, t.slab, t.nsplit, t.mn, t.out);
+    }
+    flush_slab_tasks(T, s);
+    PN2_LAUNCH_CHECK();
+    return (int)todo.size();
+}
+// forget them instead (a backward pass that died half way)
+extern "C" int pn2_mlp_drop_wgrad(void) {
+    std::lock_guard<std::mutex> lock(g_pending_mutex);
+    const int n = (int)g_pending.size();
+    g_pending.clear();
+    return n;
 }

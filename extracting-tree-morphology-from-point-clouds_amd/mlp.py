@@ -180,10 +180,54 @@ class _ChainFn(torch.autograd.Function):
         ws = torch.empty(lib.pn2_mlp_workspace_bytes(rows, arr, n, ctx.nseg), dtype=torch.uint8, device=dev)
         flops = 4 * rows * sum(int(a.cin) * int(a.cout) for a in arr)
         nbytes = 4 * rows * (cin0 + 5 * sum(int(a.cout) for a in arr))
+        if _DeferredWgrad.enlist(ws):
+            flags |= _hip.CHAIN_DEFER_WGRAD
         _hip.call("mlp_chain_bwd", lib.pn2_mlp_chain_bwd_f32, x.data_ptr(), x.stride(0), rows, arr, n, int(meta["pool_k"]),
                   dout.data_ptr(), _hip.ptr(arg), _hip.ptr(dx), cin0, skip, sa.data_ptr(), sb.data_ptr(), seg_ptr, flags,
                   ws.data_ptr(), ws.numel(), _hip.stream_ptr(), nbytes=nbytes, flops=flops)
         return (dx, None, *grads)
+
+
+class _DeferredWgrad:
+    """Weight-gradient slab reductions of a whole backward pass in one launch (PN2_CHAIN_DEFER_WGRAD): every chain backward
+    leaves its slabs in its workspace, the reductions run from an autograd-engine callback when the pass has finished --
+    before loss.backward() returns, so nobody sees a weight gradient without them.  The workspaces are kept alive here
+    until then.  Passes are told apart by the engine's graph-task id: reductions left behind by a pass that died are
+    dropped when the next one starts.  PN2_NO_DEFER_WGRAD=1 reduces per chain call."""
+    task_id = None
+    workspaces = []
+
+    @classmethod
+    def enabled(cls):
+        return not os.environ.get("PN2_NO_DEFER_WGRAD") and hasattr(torch._C, "_current_graph_task_id")
+
+    @classmethod
+    def enlist(cls, ws):
+        """-> True when the calling chain backward may defer (we are inside a backward pass and a flush is queued)."""
+        if not cls.enabled():
+            return False
+        tid = torch._C._current_graph_task_id()
+        if tid < 0:
+            return False
+        if tid != cls.task_id:
+            if cls.task_id is not None or cls.workspaces:
+                _hip.lib().pn2_mlp_drop_wgrad()
+                cls.workspaces = []
+            torch.autograd.Variable._execution_engine.queue_callback(cls.flush)
+            cls.task_id = tid
+        cls.workspaces.append(ws)
+        return True
+
+    @classmethod
+    def flush(cls):
+        try:
+            if cls.workspaces:
+                st = _hip.lib().pn2_mlp_flush_wgrad(_hip.stream_ptr())
+                if st < 0:
+                    raise RuntimeError(f"pn2_mlp_flush_wgrad -> {st}")
+        finally:
+            cls.workspaces = []
+            cls.task_id = None
 
 
 class _Sub:

@@ -292,6 +292,13 @@ typedef struct pn2_segments {
  * the semantic and the offset head on the backbone features, PointNet2.py:86-87 -- leave one gradient tensor behind
  * without a separate 3 x rows x cin x 4 byte add. */
 #define PN2_CHAIN_ACCUMULATE_DX 0x100
+/* pn2_mlp_chain_bwd_f32 only, OR-ed into `precision`: leave the weight-gradient slabs of this call in its workspace and
+ * only REMEMBER their reduction; pn2_mlp_flush_wgrad(stream) then reduces the slabs of every such call since the last
+ * flush in one launch (one launch per chain is 5-8 us of mostly latency, 12 of them per backward pass of the depth-4
+ * model).  The caller keeps the workspaces alive until the flush and flushes before anything reads the weight gradients
+ * (pn2_amd/mlp.py: an autograd-engine callback at the end of the backward pass).  pn2_mlp_drop_wgrad() forgets pending
+ * reductions (a pass that died). */
+#define PN2_CHAIN_DEFER_WGRAD 0x200
 
 size_t pn2_mlp_workspace_bytes(int rows, const pn2_mlp_layer *layers, int nlayers, int nseg);
 int pn2_mlp_chain_fwd_f32(const float *x, int64_t ldx, int rows, const pn2_mlp_layer *layers, int nlayers,
@@ -301,6 +308,8 @@ int pn2_mlp_chain_bwd_f32(const float *x, int64_t ldx, int rows, const pn2_mlp_l
                           int pool_k, const float *dout, const int32_t *pool_arg, float *dx, int64_t lddx,
                           int dx_first_col, float *scratch_a, float *scratch_b, const pn2_segments *segments,
                           int precision, void *workspace, size_t workspace_bytes, void *stream);
+int pn2_mlp_flush_wgrad(void *stream); /* -> number of reductions launched, or < 0 */
+int pn2_mlp_drop_wgrad(void);
 
 /* ---------------------------------------------------------------------------------------------------
  * Closest-cylinder projection       replaces Modules/Projection.py:19-114 (closest_cylinder_cuda_batch; duplicated at

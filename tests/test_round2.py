@@ -646,3 +646,55 @@ def test_ball_query_by_cells_matches_oracle(pn2, case):
         scan = ops.ball_query(r, K, dense, q)
     assert np.array_equal(scan.cpu().numpy(), want)
     assert np.array_equal(got.cpu().numpy(), want)
+
+
+@pytest.mark.gpu
+def test_deferred_weight_gradients_and_head_pair(pn2):
+    """Weight-gradient slab reductions deferred to the engine callback at the end of the backward pass (default) against
+    reductions per chain call (PN2_NO_DEFER_WGRAD): not a bit differs on a stack of chains (same slabs, same summation
+    order), and nothing is left pending when backward() returns.  On the real model (whose grouping backward uses float
+    atomics, so runs differ in the last bits anyway) the three ways -- deferred, per chain, heads as separate autograd
+    nodes (PN2_NO_CHAIN_PAIR) -- agree to 2e-3 of the largest gradient."""
+    import torch.nn as nn
+    from pn2_amd import mlp, _hip
+    from pn2_amd.PointNet2.PointNet2 import PointNet2
+    from pn2_amd.synthetic import gaussian_branch_tree
+
+    def stack():
+        torch.manual_seed(0)
+        mk = lambda ci, co: (nn.Conv1d(ci, co, 1).cuda(), nn.BatchNorm1d(co).cuda().train(), True)
+        return [[mk(35, 64), mk(64, 64)], [mk(64, 128), mk(128, 32)], [mk(32, 32)]]
+
+    x = torch.randn(5000, 35, device="cuda")
+    got = {}
+    for mode, e in (("deferred", {}), ("per_chain", {"PN2_NO_DEFER_WGRAD": 1})):
+        chains = stack()
+        with env(**e):
+            y = x
+            for layers in chains:
+                y = mlp.chain_rows(y, layers)
+            (y * y).sum().backward()
+            assert _hip.lib().pn2_mlp_drop_wgrad() == 0, "weight-gradient reductions left pending after backward()"
+        got[mode] = [p.grad.clone() for layers in chains for conv, bn, _ in layers for p in (conv.weight, bn.weight, bn.bias)]
+    assert all(torch.equal(a, b) for a, b in zip(got["deferred"], got["per_chain"]))
+    assert all(float(g.abs().max()) > 0 for g in got["deferred"])
+
+    xyz, off, _ = gaussian_branch_tree(20000, seed=3)
+    n = len(xyz)
+    batch = {"coords": dev(xyz.T[None].copy()), "feats": dev(np.ones((1, 4, n), np.float32)),
+             "semantic_labels": torch.zeros(n, dtype=torch.long, device="cuda"), "offset_labels": dev(off),
+             "masks_off": torch.ones(n, dtype=torch.bool, device="cuda"), "masks_pad": torch.ones(1, n, dtype=torch.bool, device="cuda")}
+    grads = {}
+    for mode, e in (("deferred", {}), ("per_chain", {"PN2_NO_DEFER_WGRAD": 1}), ("separate_heads", {"PN2_NO_CHAIN_PAIR": 1})):
+        torch.manual_seed(0)
+        model = PointNet2(depth=4).cuda().train()
+        torch.manual_seed(1)
+        with env(**e):
+            loss, _ = model(batch, return_loss=True)
+            loss.backward()
+            assert _hip.lib().pn2_mlp_drop_wgrad() == 0
+        grads[mode] = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    gmax = max(float(g.abs().max()) for g in grads["deferred"].values())
+    for other in ("per_chain", "separate_heads"):
+        for k, g in grads["deferred"].items():
+            assert float((g - grads[other][k]).abs().max()) <= 2e-3 * gmax, (other, k)
