@@ -82,14 +82,17 @@ class PointNet2(nn.Module):
         """batch: coords [B,3,N], feats [B,F,N] (+ masks/labels when return_loss).  Reference lines 118-134."""
         output = dict()
         with batched_counters():        # one launch for all BatchNorm step counters of the pass
-            output["backbone_feats"] = self.forward_backbone(coords=batch["coords"], feats=batch["feats"])
-            output["semantic_prediction_logits"], output["offset_predictions"] = self._heads(output["backbone_feats"])
+            # with a loss to compute nobody sees the backbone features: fp1 leaves its last BatchNorm + ReLU to the heads
+            feats = self.forward_backbone(coords=batch["coords"], feats=batch["feats"], lazy_rows=bool(return_loss))
+            if not isinstance(feats, tuple):
+                output["backbone_feats"] = feats
+            output["semantic_prediction_logits"], output["offset_predictions"] = self._heads(feats)
         if return_loss:
             output = self.get_loss(model_output=output, **batch)
         return output
 
     @cuda_cast
-    def forward_backbone(self, coords, feats, **kwargs):
+    def forward_backbone(self, coords, feats, lazy_rows=False, **kwargs):
         """SA x L then FP x L; always fp32 (the reference disables autocast here, lines 136-178)."""
         n = len(_SA[self.depth])
         with torch.amp.autocast("cuda", enabled=False):
@@ -101,13 +104,19 @@ class PointNet2(nn.Module):
                 pts.append(npts)
             for level in range(n, 1, -1):
                 pts[level - 1] = getattr(self, f"fp{level}")(xyz[level - 1], xyz[level], pts[level - 1], pts[level])
+            if lazy_rows:     # -> (rows or mlp.LazyRows, B, N): the heads apply fp1's last BatchNorm + ReLU themselves
+                return self.fp1(xyz[0], xyz[1], None, pts[1], lazy_rows=True)
             return self.fp1(xyz[0], xyz[1], None, pts[1])
 
     def _heads(self, feats):
-        """feats [B,128,N] -> (semantic logits [B,2,N], offsets [B,3,N]): the two ConvHeads (reference lines 128-129) as one
-        autograd node, so that their common input gets ONE gradient tensor instead of two and a sum."""
-        B, C, N = feats.shape
-        rows = feats.permute(0, 2, 1).reshape(B * N, C)
+        """feats [B,128,N] -- or the (rows, B, N) of forward_backbone(lazy_rows=True) -- -> (semantic logits [B,2,N], offsets
+        [B,3,N]): the two ConvHeads (reference lines 128-129) as one autograd node, so that their common input gets ONE
+        gradient tensor instead of two and a sum."""
+        if isinstance(feats, tuple):
+            rows, B, N = feats
+        else:
+            B, C, N = feats.shape
+            rows = feats.permute(0, 2, 1).reshape(B * N, C)
         sem, off = chain_pair_rows(rows, self.semantic_linear._layers(), self.offset_linear._layers())
         return sem.view(B, N, -1).permute(0, 2, 1), off.view(B, N, -1).permute(0, 2, 1)
 

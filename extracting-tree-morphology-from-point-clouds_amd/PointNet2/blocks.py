@@ -154,9 +154,11 @@ class PointNetFeaturePropagation(nn.Module):
             self.mlp_bns.append(nn.BatchNorm1d(out_c))
             c = out_c
 
-    def forward(self, xyz1, xyz2, points1, points2):
+    def forward(self, xyz1, xyz2, points1, points2, lazy_rows=False):
         """xyz1 [B,3,N] dense, xyz2 [B,3,S] sampled, points1 [B,D1,N] or None, points2 [B,D2,S] -> [B,D',N]
-        (reference blocks.py:174-216): 3-NN inverse-distance interpolation, skip concat, MLP."""
+        (reference blocks.py:174-216): 3-NN inverse-distance interpolation, skip concat, MLP.
+        lazy_rows: return (rows, B, N) with rows a mlp.LazyRows when the last BatchNorm + ReLU can be left to the consumer
+        (the prediction heads, linked chains) -- otherwise ([B*N, D'] rows, B, N)."""
         x1, x2 = xyz1.permute(0, 2, 1), xyz2.permute(0, 2, 1)
         p2 = points2.permute(0, 2, 1)
         p1 = None if points1 is None else points1.permute(0, 2, 1)
@@ -169,5 +171,7 @@ class PointNetFeaturePropagation(nn.Module):
         else:
             idx, w = ops.three_nn(x1, x2)
             feats = ops.ThreeInterpolateConcat.apply(p1, p2, idx, w)
-        y = chain_rows(feats.reshape(B * N, -1), [(c, b, True) for c, b in zip(self.mlp_convs, self.mlp_bns)])
+        y = chain_rows(feats.reshape(B * N, -1), [(c, b, True) for c, b in zip(self.mlp_convs, self.mlp_bns)], lazy_out=lazy_rows)
+        if lazy_rows:
+            return y, B, N
         return y.view(B, N, -1).permute(0, 2, 1)

@@ -24,7 +24,9 @@ class MLPLayer(ctypes.Structure):
     _fields_ = [("cin", ctypes.c_int32), ("cout", ctypes.c_int32), ("weight", _vp), ("bias", _vp),
                 ("has_bn", ctypes.c_int32), ("relu", ctypes.c_int32), ("gamma", _vp), ("beta", _vp),
                 ("running_mean", _vp), ("running_var", _vp), ("eps", _f32), ("momentum", _f32),
-                ("y", _vp), ("stats", _vp), ("dweight", _vp), ("dbias", _vp), ("dgamma", _vp), ("dbeta", _vp)]
+                ("y", _vp), ("stats", _vp), ("dweight", _vp), ("dbias", _vp), ("dgamma", _vp), ("dbeta", _vp),
+                ("in_stats", _vp), ("in_relu", ctypes.c_int32), ("in_partial", _vp), ("out_partial", _vp),
+                ("out_partial_rows", ctypes.c_int32), ("out_partial_cpb", ctypes.c_int32)]
 
 
 _lp = ctypes.POINTER(MLPLayer)
@@ -84,6 +86,7 @@ SIGNATURES = {
                                 ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _int]),
     "pn2_mlp_workspace_bytes": (_sz, [_int, _lp, _int, _int]),
     "pn2_mlp_chain_fwd_f32": (_int, [_vp, _i64, _int, _lp, _int, _int, _int, _vp, _vp, _sp, _int, _vp, _sz, _vp]),
+    "pn2_mlp_link_partial_bytes": (_sz, [_int, _int, _int, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "pn2_mlp_flush_wgrad": (_int, [_vp]),
     "pn2_mlp_drop_wgrad": (_int, []),
     "pn2_mlp_chain_bwd_f32": (_int, [_vp, _i64, _int, _lp, _int, _int, _vp, _vp, _vp, _i64, _int, _vp, _vp, _sp, _int, _vp, _sz, _vp]),
@@ -107,6 +110,7 @@ _lib = None
 ABI_VERSION = 3                      # PN2_ABI_VERSION of include/pn2_hip.h
 CHAIN_ACCUMULATE_DX = 0x100          # PN2_CHAIN_ACCUMULATE_DX
 CHAIN_DEFER_WGRAD = 0x200            # PN2_CHAIN_DEFER_WGRAD
+CHAIN_LAZY_OUT = 0x400               # PN2_CHAIN_LAZY_OUT
 STATUS_FPS_HANDOFF, STATUS_FPS_ARRIVAL, STATUS_BAD_INDEX = 1, 2, 4   # PN2_STATUS_* bits
 
 

@@ -1575,6 +1575,9 @@ int launch_bn_bwd_finalize(const float* partial, const FinScratch& fs, const Seg
 
 }  // namespace
 
+// row-block size of the dgrad that produces a linked chain's input gradient (two partial chunks per block)
+inline int link_tile(int rows, int cin) { return pick_tile(rows, cin, 1); }
+
 // ===================================================================================================== C ABI
 extern "C" size_t pn2_mlp_workspace_bytes(int rows, const pn2_mlp_layer* layers, int nlayers, int nseg) {
     if (rows <= 0 || !layers || nlayers <= 0) return 0;
@@ -1614,7 +1617,11 @@ size_t slab_arena_offset(int rows, const pn2_mlp_layer* layers, int nlayers, int
 extern "C" int pn2_mlp_chain_fwd_f32(const float* x, int64_t ldx, int rows, const pn2_mlp_layer* layers, int nlayers,
                                      int training, int pool_k, float* out, int32_t* pool_arg, const pn2_segments* segments,
                                      int precision, void* workspace, size_t workspace_bytes, void* stream) {
-    if (!x || !layers || nlayers <= 0 || rows <= 0 || !out || (pool_k > 1 && (!pool_arg || rows % pool_k))) return PN2_E_BADARG;
+    const bool lazy_out = (precision & PN2_CHAIN_LAZY_OUT) != 0;
+    precision &= ~PN2_CHAIN_LAZY_OUT;
+    if (!x || !layers || nlayers <= 0 || rows <= 0 || (!out && !lazy_out) || (pool_k > 1 && (!pool_arg || rows % pool_k)))
+        return PN2_E_BADARG;
+    if (lazy_out && (pool_k > 1 || !layers[nlayers - 1].has_bn)) return PN2_E_BADARG;
     if (precision != PN2_PRECISION_F32 && precision != PN2_PRECISION_BF16) return PN2_E_BADARG;
     t_precision = precision;
     if (!segs_valid(rows, segments, pool_k)) return PN2_E_BADARG;
@@ -1623,7 +1630,7 @@ extern "C" int pn2_mlp_chain_fwd_f32(const float* x, int64_t ldx, int rows, cons
     hipStream_t s = (hipStream_t)stream;
     const FinScratch sp = fin_scratch(workspace, S.nseg, chain_cmax(layers, nlayers));   // segmented finalizes' scratch
     workspace = (char*)workspace + slice_region_of(rows, layers, nlayers, S.nseg);
-    Act in{x, ldx, nullptr, 0};
+    Act in{x, ldx, layers[0].in_stats, layers[0].in_stats ? layers[0].in_relu : 0};   // linked chain: BN(+ReLU) while staging
     for (int i = 0; i < nlayers; ++i) {
         const pn2_mlp_layer& L = layers[i];
         if (!L.weight || L.cin <= 0 || L.cout <= 0) return PN2_E_BADARG;
@@ -1664,7 +1671,7 @@ extern "C" int pn2_mlp_chain_fwd_f32(const float* x, int64_t ldx, int rows, cons
             if (L.relu && !last) return PN2_E_BADARG;  // ReLU without BatchNorm only exists fused into a BN layer here
             in = Act{y, L.cout, nullptr, 0};
         }
-        if (last && !direct_out) {
+        if (last && !direct_out && !lazy_out) {
             const int C = L.cout;
             if (!L.has_bn || C % 4) return PN2_E_BADARG;
             int nblk = 0;
@@ -1732,7 +1739,13 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
         // ---- BatchNorm backward reductions -> coefficients a, b and dgamma, dbeta
         if (L.has_bn) {
             int R = fused_R, cpb = fused_cpb, st;
-            if (!fused_R) {   // otherwise written by the dgrad epilogue (or the narrow backward kernel) of layer i + 1
+            const float* partial = (const float*)ws;
+            if (last && L.out_partial && pool_k <= 1) {   // written by the linked consumer chain's dgrad epilogue
+                partial = L.out_partial;
+                R = L.out_partial_rows;
+                cpb = L.out_partial_cpb;
+                if (R <= 0 || cpb <= 0) return PN2_E_BADARG;
+            } else if (!fused_R) {   // otherwise written by the dgrad epilogue (or the narrow backward kernel) of layer i + 1
                 R = RB;
                 cpb = 1;
                 int nblk = 0;
@@ -1746,7 +1759,7 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
                                lddz, y, (long long)L.cout, rows, L.cout, (const float*)L.stats, L.relu, ws, tb);
                 PN2_LAUNCH_CHECK();
             }
-            if ((st = launch_bn_bwd_finalize((const float*)ws, sp, S, R, cpb, rows, L, s))) return st;
+            if ((st = launch_bn_bwd_finalize(partial, sp, S, R, cpb, rows, L, s))) return st;
         } else if (L.dbias && !(narrow_ok(L, last, pool_k) && lddz == L.cout)) {
             const int nblk = pn2::ceil_div(rows, CS_ROWS);
             PN2_LAUNCH("colsum", 4.0 * rows * L.cout, 0, colsum_kernel, dim3(nblk), dim3(256), s, dz, lddz, rows, L.cout, ws);
@@ -1756,7 +1769,7 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
         }
         fused_R = fused_cpb = 0;
         // layer input as an activation source
-        Act in = i == 0 ? Act{x, ldx, nullptr, 0}
+        Act in = i == 0 ? Act{x, ldx, layers[0].in_stats, layers[0].in_stats ? layers[0].in_relu : 0}
                         : Act{layers[i - 1].y, layers[i - 1].cout, layers[i - 1].has_bn ? layers[i - 1].stats : nullptr,
                               layers[i - 1].relu};
         // ---- narrow last layer: one vector-ALU pass does dgrad, wgrad, bias sums and the previous layer's BN sums
@@ -1847,6 +1860,13 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
                 g.erelu = layers[i - 1].relu;
                 fused_R = tile;
                 fused_cpb = 2;
+            } else if (i == 0 && in.coef && L.in_partial) {   // linked chain: the producing layer's BatchNorm-backward sums
+                if (skip || tile != link_tile(rows, L.cin)) return PN2_E_BADARG;
+                g.partial = L.in_partial;
+                g.ey = x;
+                g.ldey = ldx;
+                g.ecoef = in.coef;
+                g.erelu = in.relu;
             }
             int st = L.has_bn ? launch_gemm<true, TR_DY, false, TR_PLAIN, EPI_STORE>(g, S, tile, s)
                               : launch_gemm<true, TR_PLAIN, false, TR_PLAIN, EPI_STORE>(g, S, tile, s);
@@ -1868,6 +1888,14 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
 
 // The weight-gradient reductions of every pn2_mlp_chain_bwd_f32 call made with PN2_CHAIN_DEFER_WGRAD since the last flush,
 // in as few launches as the task table allows (32 tasks each).  The workspaces of those calls must still be alive.
+extern "C" size_t pn2_mlp_link_partial_bytes(int rows, int cin, int nseg, int32_t* block_rows, int32_t* chunks_per_block) {
+    if (rows <= 0 || cin <= 0) return 0;
+    if (nseg < 1) nseg = 1;
+    if (block_rows) *block_rows = link_tile(rows, cin);
+    if (chunks_per_block) *chunks_per_block = 2;
+    return ((size_t)pn2::ceil_div(rows, 32) + 2 * (size_t)nseg) * 2 * (size_t)cin * sizeof(float);
+}
+
 extern "C" int pn2_mlp_flush_wgrad(void* stream) {
     std::vector<SlabTask> todo;
     {

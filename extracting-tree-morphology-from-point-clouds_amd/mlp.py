@@ -74,6 +74,10 @@ class _ChainFn(torch.autograd.Function):
         nseg = 1 if seg_ptr is None else len(meta["seg_off"]) - 1
         dev = x.device
         arr = (_hip.MLPLayer * n)()
+        link = meta.get("link")                         # LazyRows of the producing chain: x is its pre-activation rows
+        if link is not None:
+            arr[0].in_stats, arr[0].in_relu = link.stats.data_ptr(), int(link.relu)
+        lazy_out = bool(meta.get("lazy_out"))
         ys, stats = [], []
         cin = cin0
         for i, spec in enumerate(meta["layers"]):
@@ -100,6 +104,8 @@ class _ChainFn(torch.autograd.Function):
         if pool_k > 1:
             out = torch.empty(rows // pool_k, cout_last, dtype=torch.float32, device=dev)
             arg = torch.empty(rows // pool_k, cout_last, dtype=torch.int32, device=dev)
+        elif lazy_out:
+            out, arg = None, None                       # the consumer reads ys[-1] through stats[-1]
         else:
             out = torch.empty(rows, cout_last, dtype=torch.float32, device=dev)
             arg = None
@@ -108,8 +114,8 @@ class _ChainFn(torch.autograd.Function):
         flops = 2 * rows * sum(int(a.cin) * int(a.cout) for a in arr)
         nbytes = 4 * rows * (cin0 + 2 * sum(int(a.cout) for a in arr))
         _hip.call("mlp_chain_fwd", lib.pn2_mlp_chain_fwd_f32, x.data_ptr(), x.stride(0), rows, arr, n, int(training),
-                  int(pool_k), out.data_ptr(), _hip.ptr(arg), seg_ptr, precision, ws.data_ptr(), ws.numel(), _hip.stream_ptr(),
-                  nbytes=nbytes, flops=flops)
+                  int(pool_k), _hip.ptr(out), _hip.ptr(arg), seg_ptr, precision | (_hip.CHAIN_LAZY_OUT if lazy_out else 0),
+                  ws.data_ptr(), ws.numel(), _hip.stream_ptr(), nbytes=nbytes, flops=flops)
         ctx.meta = meta
         ctx.nseg = nseg
         ctx.precision = precision
@@ -117,10 +123,16 @@ class _ChainFn(torch.autograd.Function):
         ctx.dims = (rows, cin0)
         ctx.save_for_backward(x, arg, *[t for t in ys if t is not None], *[t for t in stats if t is not None], *params)
         ctx.layout = ([t is not None for t in ys], [t is not None for t in stats])
+        ctx.link = link                                  # keeps the producer's coefficient blocks alive for the backward
+        if lazy_out:
+            # what leaves is the last layer's PRE-activation rows; the gradient that comes back for it is the gradient with
+            # respect to the activated rows (chain_pair_rows / chain_rows(link=...) are the only consumers): see LazyRows
+            ctx.mark_non_differentiable(stats[-1])
+            return ys[-1], stats[-1]
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, *_):
         lib = _hip.lib()
         meta = ctx.meta
         if not meta["training"] and any(sp["has_bn"] for sp in meta["layers"]):
@@ -182,9 +194,27 @@ class _ChainFn(torch.autograd.Function):
         nbytes = 4 * rows * (cin0 + 5 * sum(int(a.cout) for a in arr))
         if _DeferredWgrad.enlist(ws):
             flags |= _hip.CHAIN_DEFER_WGRAD
+        # linked chains: BatchNorm-backward column sums handed from the consumer's dgrad epilogue to the producer
+        handed = (meta.get("lazy_handle") or {}).pop("partial", None)
+        if handed is not None:                            # this chain produced a LazyRows and its consumer did the sums
+            arr[n - 1].out_partial, arr[n - 1].out_partial_rows, arr[n - 1].out_partial_cpb = handed[0].data_ptr(), handed[1], handed[2]
+        else:
+            arr[n - 1].out_partial = None
+        emit = None
+        link = getattr(ctx, "link", None)
+        if (link is not None and dx is not None and skip == 0 and getattr(ctx, "dx_is_complete", True)
+                and not link.handle.get("shared") and not os.environ.get("PN2_NO_LINK_SUMS")):
+            r_, c_ = ctypes.c_int32(0), ctypes.c_int32(0)
+            nb = lib.pn2_mlp_link_partial_bytes(rows, cin0, ctx.nseg, ctypes.byref(r_), ctypes.byref(c_))
+            emit = (torch.empty(nb, dtype=torch.uint8, device=dev), int(r_.value), int(c_.value))
+            arr[0].in_partial = emit[0].data_ptr()
+        else:
+            arr[0].in_partial = None
         _hip.call("mlp_chain_bwd", lib.pn2_mlp_chain_bwd_f32, x.data_ptr(), x.stride(0), rows, arr, n, int(meta["pool_k"]),
                   dout.data_ptr(), _hip.ptr(arg), _hip.ptr(dx), cin0, skip, sa.data_ptr(), sb.data_ptr(), seg_ptr, flags,
                   ws.data_ptr(), ws.numel(), _hip.stream_ptr(), nbytes=nbytes, flops=flops)
+        if emit is not None:
+            link.handle["partial"] = emit
         return (dx, None, *grads)
 
 
@@ -257,6 +287,7 @@ class _ChainPairFn(torch.autograd.Function):
         need = ctx.needs_input_grad
         a.needs_input_grad = (need[0], False) + tuple(need[4:4 + n_a])
         b.needs_input_grad = (need[0], False) + tuple(need[4 + n_a:])
+        a.dx_is_complete = False                       # the second chain adds to it: only that one can do the producer's sums
         ga = _ChainFn.backward(a, da)
         b.dx_into = ga[0]
         gb = _ChainFn.backward(b, db)
@@ -282,6 +313,24 @@ class batched_counters:
                 by_inc.setdefault(inc, []).append(t)
             for inc, ts in by_inc.items():
                 torch._foreach_add_(ts, inc)
+
+
+class LazyRows:
+    """Output of chain_rows(..., lazy_out=True): the last layer's pre-activation rows `y` [R, C] and its BatchNorm
+    coefficient block(s) `stats`; the activated rows relu(bn(y)) are never written.  Only a LINKED chain consumes it
+    (chain_rows / chain_pair_rows given a LazyRows as x): it applies the activation while staging its operand, and hands
+    back the gradient with respect to the activated rows -- which is what the producing chain's backward takes as dout."""
+
+    def __init__(self, y, stats, relu, seg_off, handle=None):
+        self.y, self.stats, self.relu, self.seg_off = y, stats, relu, seg_off
+        # shared with the producing chain's backward: the consumer leaves the BatchNorm-backward sums of the producing layer
+        # here (handle["partial"] = (buffer, block rows, chunks per block)) when it has computed the complete gradient
+        self.handle = handle if handle is not None else {}
+        self.consumed = False
+
+    @property
+    def shape(self):
+        return self.y.shape
 
 
 def _chain_spec(layers, pool_k, seg_off, dx_first_col):
@@ -326,17 +375,42 @@ def _chain_spec(layers, pool_k, seg_off, dx_first_col):
     return meta, params
 
 
-def chain_rows(x, layers, pool_k=1, seg_off=None, dx_first_col=0):
+def _link(x, spec, seg_off):
+    """x may be a LazyRows: -> (tensor to feed, meta with the link)."""
+    if not isinstance(x, LazyRows):
+        return x, spec[0]
+    if (x.seg_off or None) != ([int(v) for v in seg_off] if seg_off is not None and len(seg_off) > 2 else None):
+        raise RuntimeError("a linked chain must use the row segments of the chain that produced its input")
+    if x.consumed and not x.handle.get("shared"):
+        raise RuntimeError("a LazyRows feeds ONE consumer (a chain, or the two chains of chain_pair_rows)")
+    meta = dict(spec[0])
+    meta["link"] = x
+    return x.y, meta
+
+
+def chain_rows(x, layers, pool_k=1, seg_off=None, dx_first_col=0, lazy_out=False):
     """x [R, C_in] fp32 rows; layers: iterable of (conv, bn_or_None, relu: bool).
     -> [R, C_out], or [R // pool_k, C_out] (max over each group of pool_k consecutive rows) when pool_k > 1.
     seg_off: optional ascending row offsets [0, ..., R] of the mini-batches the rows are made of (whole-tree execution):
     train-mode BatchNorm then works per segment, exactly as if the segments had been separate calls, and every layer's
     running statistics / num_batches_tracked advance once per segment.
-    dx_first_col: the gradient w.r.t. x is only needed from this column on (the leading columns come back as zeros)."""
+    dx_first_col: the gradient w.r.t. x is only needed from this column on (the leading columns come back as zeros).
+    lazy_out: return a LazyRows (the final BatchNorm + ReLU left to the consumer, a linked chain) when the chain ends in a
+    train-mode BatchNorm on the device; x itself may be a LazyRows."""
     spec = _chain_spec(layers, pool_k, seg_off, dx_first_col)
     if spec is None:
         return x
-    return _ChainFn.apply(x, spec[0], *spec[1])
+    xin, meta = _link(x, spec, seg_off)
+    last = meta["layers"][-1]
+    if lazy_out and last["has_bn"] and meta["training"] and pool_k == 1 and xin.is_cuda and not os.environ.get("PN2_NO_LAZY_ROWS"):
+        meta = dict(meta)
+        meta["lazy_out"] = True
+        meta["lazy_handle"] = {}
+        y, st = _ChainFn.apply(xin, meta, *spec[1])
+        return LazyRows(y, st, last["relu"], meta.get("seg_off"), meta["lazy_handle"])
+    if isinstance(x, LazyRows):
+        x.consumed = True
+    return _ChainFn.apply(xin, meta, *spec[1])
 
 
 def chain_pair_rows(x, layers_a, layers_b, seg_off=None):
@@ -344,7 +418,14 @@ def chain_pair_rows(x, layers_a, layers_b, seg_off=None):
     (out_a, out_b); one autograd node, the input gradient leaves as ONE tensor (see _ChainPairFn).  Falls back to two
     chain_rows calls when either chain is empty or starts with a narrow layer."""
     layers_a, layers_b = list(layers_a), list(layers_b)
-    if len(layers_a) < 2 or len(layers_b) < 2 or not x.is_cuda or os.environ.get("PN2_NO_CHAIN_PAIR"):
+    dev_ok = x.y.is_cuda if isinstance(x, LazyRows) else x.is_cuda
+    if len(layers_a) < 2 or len(layers_b) < 2 or not dev_ok or os.environ.get("PN2_NO_CHAIN_PAIR"):
+        if isinstance(x, LazyRows):
+            x.handle["shared"] = True                   # two separate consumers: neither sees the complete gradient
         return chain_rows(x, layers_a, seg_off=seg_off), chain_rows(x, layers_b, seg_off=seg_off)
     sa, sb = _chain_spec(layers_a, 1, seg_off, 0), _chain_spec(layers_b, 1, seg_off, 0)
-    return _ChainPairFn.apply(x, sa[0], sb[0], len(sa[1]), *sa[1], *sb[1])
+    xin, ma = _link(x, sa, seg_off)
+    _, mb = _link(x, sb, seg_off)
+    if isinstance(x, LazyRows):
+        x.consumed = True
+    return _ChainPairFn.apply(xin, ma, mb, len(sa[1]), *sa[1], *sb[1])

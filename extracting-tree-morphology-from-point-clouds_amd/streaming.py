@@ -119,7 +119,7 @@ def _sa_level(sa, xyz_t, pts_t, start, layout, rc=None):
     return new_xyz, (outs[0] if len(outs) == 1 else torch.cat(outs, dim=-1))
 
 
-def _fp_level(fp, x1, x2, p1, p2, layout, rc=None):
+def _fp_level(fp, x1, x2, p1, p2, layout, rc=None, lazy=False):
     """One feature-propagation level.  rc given: the dense side is the ragged level 0 (x1, p1 unused) and the result is
     packed rows [rows, C_out]; otherwise x1 [C,N,3], p1 [C,N,D1] or None -> [C,N,C_out]."""
     layers = [(c, b, True) for c, b in zip(fp.mlp_convs, fp.mlp_bns)]
@@ -129,7 +129,7 @@ def _fp_level(fp, x1, x2, p1, p2, layout, rc=None):
             raise RuntimeError("feature propagation from a single sampled point onto ragged clouds is not supported")
         idx, w = ops.three_nn_ragged(rc, x2)
         feats = ops.ThreeInterpolateRagged.apply(p2, idx, w, rc)
-        return chain_rows(feats, layers, seg_off=layout.rows0.tolist())
+        return chain_rows(feats, layers, seg_off=layout.rows0.tolist(), lazy_out=lazy)   # lazy: a mlp.LazyRows for the heads
     N = x1.shape[1]
     if S == 1:
         feats = p2.repeat(1, N, 1)
@@ -170,7 +170,7 @@ def backbone_and_heads(model, layout, device):
         for level in range(n, 1, -1):
             pts[level - 1] = _fp_level(getattr(model, f"fp{level}"), xyz[level - 1], xyz[level], pts[level - 1], pts[level],
                                        layout)
-        feats = _fp_level(model.fp1, None, xyz[1], None, pts[1], layout, rc=rc)
+        feats = _fp_level(model.fp1, None, xyz[1], None, pts[1], layout, rc=rc, lazy=torch.is_grad_enabled())
         seg0 = layout.rows0.tolist()
         sem, off = chain_pair_rows(feats, model.semantic_linear._layers(), model.offset_linear._layers(), seg_off=seg0)
     return sem, off

@@ -263,6 +263,22 @@ typedef struct pn2_mlp_layer {
     float *y;                  /* [rows][cout] pre-BatchNorm output (written by fwd, read by bwd) */
     float *stats;              /* [8][cout] */
     float *dweight, *dbias, *dgamma, *dbeta;
+    /* layers[0] only -- a chain LINKED to the one that produced its input: `x` then holds the PRE-activation rows of that
+     * chain's last BatchNorm layer (its `y`) and in_stats that layer's coefficient block(s) ([nseg][8][cin], same segments);
+     * BatchNorm (+ ReLU when in_relu) is applied while the rows are staged, as between the layers of one chain, and the
+     * producing chain need not materialise its output (PN2_CHAIN_LAZY_OUT).  The input gradient `dx` is the gradient with
+     * respect to the ACTIVATED rows, i.e. exactly what the producing chain's backward expects as `dout`.  NULL: plain rows. */
+    const float *in_stats;
+    int32_t in_relu;
+    /* Linked chains, backward.  The chain that computes the COMPLETE gradient of the linked rows (the only consumer, or the
+     * accumulating second one of a pair) can leave the BatchNorm-backward column sums of the producing layer behind -- its
+     * dgrad epilogue has every dX element in registers -- so that the producing chain's backward does not read dout and y
+     * once more just to form them.  Consumer: layers[0].in_partial = a buffer of pn2_mlp_link_partial_bytes() (NULL: off;
+     * needs dx_first_col == 0).  Producer: layers[nlayers-1].out_partial = that buffer, out_partial_rows / _cpb = the row
+     * block size and chunks per block the helper reported. */
+    float *in_partial;
+    const float *out_partial;
+    int32_t out_partial_rows, out_partial_cpb;
 } pn2_mlp_layer;
 
 /* Row segments (whole-tree execution).  The reference's streaming mode runs the mini-batches of a tree one after the
@@ -299,6 +315,10 @@ typedef struct pn2_segments {
  * (pn2_amd/mlp.py: an autograd-engine callback at the end of the backward pass).  pn2_mlp_drop_wgrad() forgets pending
  * reductions (a pass that died). */
 #define PN2_CHAIN_DEFER_WGRAD 0x200
+/* pn2_mlp_chain_fwd_f32 only, OR-ed into `precision`: the last layer ends in a BatchNorm and its activation is NOT written
+ * (`out` may be NULL): the consumer is a linked chain (pn2_mlp_layer.in_stats) that reads `y` and `stats` of that layer.
+ * Saves one read and one write of rows x cout floats.  Not with pool_k > 1. */
+#define PN2_CHAIN_LAZY_OUT 0x400
 
 size_t pn2_mlp_workspace_bytes(int rows, const pn2_mlp_layer *layers, int nlayers, int nseg);
 int pn2_mlp_chain_fwd_f32(const float *x, int64_t ldx, int rows, const pn2_mlp_layer *layers, int nlayers,
@@ -308,6 +328,7 @@ int pn2_mlp_chain_bwd_f32(const float *x, int64_t ldx, int rows, const pn2_mlp_l
                           int pool_k, const float *dout, const int32_t *pool_arg, float *dx, int64_t lddx,
                           int dx_first_col, float *scratch_a, float *scratch_b, const pn2_segments *segments,
                           int precision, void *workspace, size_t workspace_bytes, void *stream);
+size_t pn2_mlp_link_partial_bytes(int rows, int cin, int nseg, int32_t *block_rows, int32_t *chunks_per_block);
 int pn2_mlp_flush_wgrad(void *stream); /* -> number of reductions launched, or < 0 */
 int pn2_mlp_drop_wgrad(void);
 

@@ -698,3 +698,37 @@ def test_deferred_weight_gradients_and_head_pair(pn2):
     for other in ("per_chain", "separate_heads"):
         for k, g in grads["deferred"].items():
             assert float((g - grads[other][k]).abs().max()) <= 2e-3 * gmax, (other, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("segments", [False, True])
+def test_linked_chains_equal_materialised_rows(pn2, segments):
+    """A chain that leaves its last BatchNorm + ReLU to the two head chains reading it (mlp.LazyRows: no activated rows in
+    memory, the heads' second dgrad hands the BatchNorm-backward sums back) against the same stack with the rows
+    materialised (PN2_NO_LAZY_ROWS): outputs bit-identical (the staging transform is the apply kernel's expression),
+    gradients equal up to the summation order of the handed-over sums."""
+    import torch.nn as nn
+    from pn2_amd import mlp
+
+    def build():
+        torch.manual_seed(0)
+        mk = lambda ci, co, bn=True: (nn.Conv1d(ci, co, 1).cuda(), nn.BatchNorm1d(co).cuda().train() if bn else None, bn)
+        return [mk(35, 64), mk(64, 128)], [mk(128, 128), mk(128, 2, False)], [mk(128, 128), mk(128, 3, False)]
+
+    rows = 6000
+    seg = [0, 1500, 1500 + 2600, rows] if segments else None
+    x0 = torch.randn(rows, 35, device="cuda")
+    res = {}
+    for mode, e in (("linked", {}), ("materialised", {"PN2_NO_LAZY_ROWS": 1})):
+        trunk, ha, hb = build()
+        x = x0.clone().requires_grad_(True)
+        with env(**e):
+            feats = mlp.chain_rows(x, trunk, seg_off=seg, lazy_out=True)
+            assert isinstance(feats, mlp.LazyRows) == (mode == "linked")
+            a, b = mlp.chain_pair_rows(feats, ha, hb, seg_off=seg)
+            ((a * a).sum() + (b * torch.arange(3, device="cuda")).sum()).backward()
+        params = [p for chain in (trunk, ha, hb) for conv, bn, _ in chain for p in ([conv.weight] + ([bn.weight, bn.bias] if bn else [conv.bias]))]
+        res[mode] = (a.detach(), b.detach(), x.grad.clone(), [p.grad.clone() for p in params])
+    assert torch.equal(res["linked"][0], res["materialised"][0]) and torch.equal(res["linked"][1], res["materialised"][1])
+    for g, h in zip([res["linked"][2]] + res["linked"][3], [res["materialised"][2]] + res["materialised"][3]):
+        assert float((g - h).norm()) <= 2e-5 * float(h.norm()) + 1e-7, (float((g - h).norm()), float(h.norm()))
