@@ -220,6 +220,7 @@ struct GemmArgs {
     long long ldey;
     const float* ecoef;
     int erelu;
+    long long pstride;    // partial layout: 0 = [chunk][2][N] (row-major); else channel-major, column c at c * pstride + 2 * chunk
     int accumulate;       // EPI_STORE: C += result (PN2_CHAIN_ACCUMULATE_DX): the accumulators START from C -- the loads
                           // travel with the first K-tile's instead of forming a read-modify-write chain in the epilogue
 };
@@ -275,8 +276,12 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& g, f32x16 (&a
                 }
             m2 += __shfl_xor(m2, 32, 64);
             if (half == 0 && cok && m0 + wm * WT < g.M) {
-                g.partial[(chunk * 2 + 0) * g.N + col] = mean;
-                g.partial[(chunk * 2 + 1) * g.N + col] = m2;
+                if (g.pstride) {
+                    *(float2*)(g.partial + (long long)col * g.pstride + chunk * 2) = make_float2(mean, m2);
+                } else {
+                    g.partial[(chunk * 2 + 0) * g.N + col] = mean;
+                    g.partial[(chunk * 2 + 1) * g.N + col] = m2;
+                }
             }
         }
         if (EPI == EPI_STORE && g.partial) {
@@ -300,8 +305,12 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& g, f32x16 (&a
             s1 += __shfl_xor(s1, 32, 64);
             s2 += __shfl_xor(s2, 32, 64);
             if (half == 0 && cok && m0 + wm * WT < g.M) {
-                g.partial[(chunk * 2 + 0) * g.N + col] = s1;
-                g.partial[(chunk * 2 + 1) * g.N + col] = s2;
+                if (g.pstride) {
+                    *(float2*)(g.partial + (long long)col * g.pstride + chunk * 2) = make_float2(s1, s2);
+                } else {
+                    g.partial[(chunk * 2 + 0) * g.N + col] = s1;
+                    g.partial[(chunk * 2 + 1) * g.N + col] = s2;
+                }
             }
         }
     }
@@ -477,17 +486,30 @@ __global__ __launch_bounds__(NT * TEAMS, (TEAMS > 1 ? 1 : (EPI == EPI_STORE ? 2 
                            (long long)blockIdx.x * (TILE / WT) + wm);
 }
 
+// (chunk, which) element of one channel's statistics partials in either layout (GemmArgs::pstride)
+struct PartialView {
+    const float* p;
+    int C, c;
+    long long cm;
+    __device__ __forceinline__ float operator()(int k, int which) const {
+        return cm ? p[(long long)c * cm + 2 * (long long)k + which] : p[((long long)k * 2 + which) * C + c];
+    }
+};
+
 // ------------------------------------------------------------------------------------------- BatchNorm: forward
 // One block per channel: merge the CH-row (mean, M2) partials in float64, write the coefficient block and
 // update the running statistics exactly like nn.BatchNorm (biased variance for normalisation, unbiased for
 // running_var).
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int rows, int CH, int C,
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial_, int rows, int CH, int C,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                          float eps, float momentum, float* __restrict__ coef) {
+                                                          float eps, float momentum, float* __restrict__ coef, long long cm) {
     __shared__ double red[256];
     __shared__ double s_mean;
     const int c = blockIdx.x, t = threadIdx.x;
+    // cm != 0: channel-major partials (the GEMM epilogues of single-segment chains): this channel's (mean, M2) pairs are
+    // contiguous -- coalesced reads instead of one useful float per cache line.  Same values, same summation order.
+    const PartialView partial{partial_, C, c, cm};
     const int nchunk = (rows + CH - 1) / CH;
     // Up to KEEP chunks per thread stay in registers between the two reductions (the strided partials are read once:
     // one useful float per cache line, the read IS the kernel's time); longer columns re-read.
@@ -500,8 +522,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
         for (int i = 0; i < KEEP; ++i) {
             const int k = t + 256 * i;
             const bool on = k < nchunk;
-            pm[i] = on ? partial[((long long)k * 2) * C + c] : 0.0f;
-            pv[i] = on ? partial[((long long)k * 2 + 1) * C + c] : 0.0f;
+            pm[i] = on ? partial(k, 0) : 0.0f;
+            pv[i] = on ? partial(k, 1) : 0.0f;
         }
 #pragma unroll
         for (int i = 0; i < KEEP; ++i) {
@@ -513,7 +535,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
 #pragma unroll 8
         for (int k = t; k < nchunk; k += 256) {  // independent strided loads: keep several in flight
             const int n = rows - k * CH < CH ? rows - k * CH : CH;
-            acc += (double)n * (double)partial[((long long)k * 2) * C + c];
+            acc += (double)n * (double)partial(k, 0);
         }
     }
     red[t] = acc;
@@ -540,8 +562,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
 #pragma unroll 8
         for (int k = t; k < nchunk; k += 256) {
             const int n = rows - k * CH < CH ? rows - k * CH : CH;
-            const double d = (double)partial[((long long)k * 2) * C + c] - mean;
-            acc += (double)partial[((long long)k * 2 + 1) * C + c] + (double)n * d * d;
+            const double d = (double)partial(k, 0) - mean;
+            acc += (double)partial(k, 1) + (double)n * d * d;
         }
     }
     __syncthreads();
@@ -569,16 +591,17 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
 }
 
 // one block per channel: s1, s2 in float64 -> dgamma, dbeta and the dY coefficients (a = s1/R, b = invstd*s2/R)
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int rows, int C,
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial_, int nblk, int rows, int C,
                                                               float* __restrict__ coef, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta) {
+                                                              float* __restrict__ dbeta, long long cm) {
     __shared__ double r1[256], r2[256];
     const int c = blockIdx.x, t = threadIdx.x;
+    const PartialView partial{partial_, C, c, cm};
     double a1 = 0.0, a2 = 0.0;
 #pragma unroll 8
     for (int k = t; k < nblk; k += 256) {
-        a1 += (double)partial[((long long)k * 2) * C + c];
-        a2 += (double)partial[((long long)k * 2 + 1) * C + c];
+        a1 += (double)partial(k, 0);
+        a2 += (double)partial(k, 1);
     }
     r1[t] = a1;
     r2[t] = a2;
@@ -1524,11 +1547,11 @@ dim3 slice_grid(const SegTable& st, int cpb, int C) {
 
 // forward finalize of one BatchNorm layer: (mean, M2) partial chunks of tile/2 rows, two per row tile of the table
 int launch_bn_finalize(const float* partial, const FinScratch& fs, const Segs& S, int tile, int rows, const pn2_mlp_layer& L,
-                       hipStream_t s) {
+                       hipStream_t s, long long cm) {
     const int ch = tile / 2;
     if (S.nseg == 1) {
         PN2_LAUNCH("bn_finalize", 8.0 * pn2::ceil_div(rows, ch) * L.cout, 0, bn_finalize_kernel, dim3(L.cout), dim3(256), s,
-                   partial, rows, ch, L.cout, L.gamma, L.beta, L.running_mean, L.running_var, L.eps, L.momentum, L.stats);
+                   partial, rows, ch, L.cout, L.gamma, L.beta, L.running_mean, L.running_var, L.eps, L.momentum, L.stats, cm);
         PN2_LAUNCH_CHECK();
         return 0;
     }
@@ -1550,12 +1573,12 @@ int launch_bn_finalize(const float* partial, const FinScratch& fs, const Segs& S
 
 // backward finalize: row blocks of `R` rows hold `cpb` partial chunks each
 int launch_bn_bwd_finalize(const float* partial, const FinScratch& fs, const Segs& S, int R, int cpb, int rows,
-                           const pn2_mlp_layer& L, hipStream_t s) {
+                           const pn2_mlp_layer& L, hipStream_t s, long long cm) {
     int nblk = 0;
     const SegTable st = make_table(S, R, &nblk);
     if (S.nseg == 1) {
         PN2_LAUNCH("bn_bwd_finalize", 8.0 * nblk * cpb * L.cout, 0, bn_bwd_finalize_kernel, dim3(L.cout), dim3(256), s, partial,
-                   pn2::ceil_div(rows, R / cpb), rows, L.cout, L.stats, L.dgamma, L.dbeta);
+                   pn2::ceil_div(rows, R / cpb), rows, L.cout, L.stats, L.dgamma, L.dbeta, cm);
         PN2_LAUNCH_CHECK();
         return 0;
     }
@@ -1574,6 +1597,12 @@ int launch_bn_bwd_finalize(const float* partial, const FinScratch& fs, const Seg
 }
 
 }  // namespace
+
+// channel-major partials of the GEMM epilogues (two chunks per row tile), single-segment chains only; 0 = row-major
+inline long long cm_stride(int rows, int tile, int nseg) {
+    static const bool off = getenv("PN2_BN_ROW_MAJOR") != nullptr;   // A/B aid
+    return (nseg == 1 && !off) ? 2ll * 2 * pn2::ceil_div(rows, tile) : 0;
+}
 
 // row-block size of the dgrad that produces a linked chain's input gradient (two partial chunks per block)
 inline int link_tile(int rows, int cin) { return pick_tile(rows, cin, 1); }
@@ -1649,6 +1678,7 @@ extern "C" int pn2_mlp_chain_fwd_f32(const float* x, int64_t ldx, int rows, cons
         g.bias = L.bias;
         g.partial = (L.has_bn && training) ? (float*)workspace : nullptr;
         const int tile = pick_tile(rows, L.cout, 1);
+        g.pstride = cm_stride(rows, tile, S.nseg);
         int st = 0;
         if (narrow_ok(L, last, pool_k) && in.ld % 4 == 0 && aligned16(in.p)) {
             st = launch_narrow_fwd(in, rows, L, y, S, s);
@@ -1659,7 +1689,7 @@ extern "C" int pn2_mlp_chain_fwd_f32(const float* x, int64_t ldx, int rows, cons
         if (st) return st;
         if (L.has_bn) {
             if (training) {
-                if ((st = launch_bn_finalize((const float*)workspace, sp, S, tile, rows, L, s))) return st;
+                if ((st = launch_bn_finalize((const float*)workspace, sp, S, tile, rows, L, s, cm_stride(rows, tile, S.nseg)))) return st;
             } else {
                 if (!L.running_mean || !L.running_var) return PN2_E_BADARG;
                 PN2_LAUNCH("bn_eval_coef", 36.0 * L.cout, 0, bn_eval_coef_kernel, dim3(pn2::ceil_div(L.cout, 256)), dim3(256), s,
@@ -1732,6 +1762,7 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
     }
     // BatchNorm-backward partials of the current layer already in ws?  (R, cpb): row-block size and chunks per block
     int fused_R = 0, fused_cpb = 0;
+    long long fused_cm = 0;   // layout of those partials (cm_stride)
     for (int i = nlayers - 1; i >= 0; --i) {
         const pn2_mlp_layer& L = layers[i];
         const bool last = i == nlayers - 1;
@@ -1739,15 +1770,18 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
         // ---- BatchNorm backward reductions -> coefficients a, b and dgamma, dbeta
         if (L.has_bn) {
             int R = fused_R, cpb = fused_cpb, st;
+            long long cm = fused_cm;
             const float* partial = (const float*)ws;
             if (last && L.out_partial && pool_k <= 1) {   // written by the linked consumer chain's dgrad epilogue
                 partial = L.out_partial;
                 R = L.out_partial_rows;
                 cpb = L.out_partial_cpb;
-                if (R <= 0 || cpb <= 0) return PN2_E_BADARG;
+                if (R <= 0 || cpb != 2) return PN2_E_BADARG;
+                cm = cm_stride(rows, R, S.nseg);
             } else if (!fused_R) {   // otherwise written by the dgrad epilogue (or the narrow backward kernel) of layer i + 1
                 R = RB;
                 cpb = 1;
+                cm = 0;
                 int nblk = 0;
                 const SegTable tb = make_table(S, RB, &nblk);
                 const bool vec = (L.cout % 4 == 0) && (lddz % 4 == 0) && aligned16(dz) && aligned16(y);
@@ -1759,7 +1793,7 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
                                lddz, y, (long long)L.cout, rows, L.cout, (const float*)L.stats, L.relu, ws, tb);
                 PN2_LAUNCH_CHECK();
             }
-            if ((st = launch_bn_bwd_finalize(partial, sp, S, R, cpb, rows, L, s))) return st;
+            if ((st = launch_bn_bwd_finalize(partial, sp, S, R, cpb, rows, L, s, cm))) return st;
         } else if (L.dbias && !(narrow_ok(L, last, pool_k) && lddz == L.cout)) {
             const int nblk = pn2::ceil_div(rows, CS_ROWS);
             PN2_LAUNCH("colsum", 4.0 * rows * L.cout, 0, colsum_kernel, dim3(nblk), dim3(256), s, dz, lddz, rows, L.cout, ws);
@@ -1768,6 +1802,7 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
             PN2_LAUNCH_CHECK();
         }
         fused_R = fused_cpb = 0;
+        fused_cm = 0;
         // layer input as an activation source
         Act in = i == 0 ? Act{x, ldx, layers[0].in_stats, layers[0].in_stats ? layers[0].in_relu : 0}
                         : Act{layers[i - 1].y, layers[i - 1].cout, layers[i - 1].has_bn ? layers[i - 1].stats : nullptr,
@@ -1860,6 +1895,7 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
                 g.erelu = layers[i - 1].relu;
                 fused_R = tile;
                 fused_cpb = 2;
+                g.pstride = fused_cm = cm_stride(rows, tile, S.nseg);
             } else if (i == 0 && in.coef && L.in_partial) {   // linked chain: the producing layer's BatchNorm-backward sums
                 if (skip || tile != link_tile(rows, L.cin)) return PN2_E_BADARG;
                 g.partial = L.in_partial;
@@ -1867,6 +1903,7 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
                 g.ldey = ldx;
                 g.ecoef = in.coef;
                 g.erelu = in.relu;
+                g.pstride = cm_stride(rows, tile, S.nseg);
             }
             int st = L.has_bn ? launch_gemm<true, TR_DY, false, TR_PLAIN, EPI_STORE>(g, S, tile, s)
                               : launch_gemm<true, TR_PLAIN, false, TR_PLAIN, EPI_STORE>(g, S, tile, s);
