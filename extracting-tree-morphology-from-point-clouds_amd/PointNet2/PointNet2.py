@@ -16,6 +16,7 @@ from .. import ops, streaming
 from ..Loss import MaskedPointLoss, point_wise_loss
 from ..mlp import batched_counters, chain_pair_rows
 from ..Utils import cuda_cast
+from .pointnet2_utils import start_batch
 from .blocks import (MLP, ConvHead, PointNetFeaturePropagation, PointNetSetAbstraction,
                      PointNetSetAbstractionMsg)
 
@@ -95,7 +96,9 @@ class PointNet2(nn.Module):
     def forward_backbone(self, coords, feats, lazy_rows=False, **kwargs):
         """SA x L then FP x L; always fp32 (the reference disables autocast here, lines 136-178)."""
         n = len(_SA[self.depth])
-        with torch.amp.autocast("cuda", enabled=False):
+        # the FPS start indices of all levels in one host-to-device copy (drawn in the levels' order: same numbers)
+        sizes = [coords.shape[2]] + [getattr(self, f"sa{level}").npoint for level in range(1, n)]
+        with torch.amp.autocast("cuda", enabled=False), start_batch(coords.shape[0], sizes, coords.device):
             xyz = [coords]
             pts = [feats if self.use_features else None]
             for level in range(1, n + 1):
@@ -154,7 +157,10 @@ class PointNet2(nn.Module):
         cum_off = torch.cumsum(off_mask, 0)
         if sem.is_cuda and semantic_labels.dtype == torch.long:
             both = MaskedPointLoss.apply(sem, off, pad, off_mask, cum_pad, cum_off, semantic_labels.reshape(-1), offset_labels)
-            semantic_loss, offset_loss = both[0], both[1]
+            # both multipliers in one multiply and the total as one reduction: the scalar arithmetic of the generic path below
+            # (two selects, two multiplies, two adds and their backward nodes) is ten launches of a few microseconds each
+            weighted = both * self._loss_weights(both.device)
+            return weighted.sum(), {"semantic_loss": weighted[0], "offset_loss": weighted[1]}
         else:
             rank = (cum_pad - 1).clamp(0, semantic_labels.numel() - 1)
             n_valid, n_off = cum_pad[-1].clamp_min(1), cum_off[-1].clamp_min(1)
@@ -167,6 +173,14 @@ class PointNet2(nn.Module):
         loss_dict = {"semantic_loss": semantic_loss * self.loss_multiplier_semantic,
                      "offset_loss": offset_loss * self.loss_multiplier_offset}
         return sum(loss_dict.values()), loss_dict
+
+    def _loss_weights(self, device):
+        w = getattr(self, "_loss_w", None)
+        key = (self.loss_multiplier_semantic, self.loss_multiplier_offset, device)
+        if w is None or w[0] != key:
+            w = (key, torch.tensor([float(key[0]), float(key[1])], dtype=torch.float32, device=device))
+            self._loss_w = w
+        return w[1]
 
     def get_loss_hierarchical(self, model_output, semantic_labels, offset_labels, **kwargs):
         semantic_loss, offset_loss = point_wise_loss(model_output["semantic_prediction_logits"].float(),

@@ -63,11 +63,47 @@ class StartIndexFeed:
             torch.randint(0, n, (host.numel(),), dtype=torch.long, out=host)
 
 
+class start_batch:
+    """Context: the start indices of the FPS calls made inside -- `sizes` = the cloud size of each, in call order -- are
+    drawn up front, one torch.randint per call in that order (the global CPU generator sees exactly the draws it would
+    see anyway), and reach the device in ONE copy instead of one 8-byte copy per level.  A call that does not match the
+    announced (B, N) sequence falls back to its own draw."""
+    active = None
+
+    def __init__(self, B, sizes, device):
+        self.todo = None
+        if StartIndexFeed.active is None and start_batch.active is None and torch.device(device).type == "cuda":
+            host = torch.empty(len(sizes), B, dtype=torch.long, pin_memory=True)
+            for row, n in zip(host, sizes):
+                torch.randint(0, int(n), (B,), dtype=torch.long, out=row)
+            dev = host.to(device, non_blocking=True)
+            self.todo = [(B, int(n), dev[i]) for i, n in enumerate(sizes)]
+
+    def __enter__(self):
+        if self.todo is not None:
+            start_batch.active = self
+        return self
+
+    def __exit__(self, *exc):
+        if start_batch.active is self:
+            start_batch.active = None
+
+    def take(self, B, N):
+        if self.todo and self.todo[0][0] == B and self.todo[0][1] == N:
+            return self.todo.pop(0)[2]
+        self.todo = []          # out of step: the remaining announced draws were made already, later calls draw for themselves
+        return None
+
+
 def _draw_start(B, N, device):
     # One draw per call from the global CPU generator, then moved to the device: same RNG stream
     # consumption as the reference (:79), so seeded runs pick the same first centroid.
     if StartIndexFeed.active is not None:
         return StartIndexFeed.active.take(B, N, device)
+    if start_batch.active is not None:
+        got = start_batch.active.take(B, N)
+        if got is not None:
+            return got
     return torch.randint(0, N, (B,), dtype=torch.long, pin_memory=True).to(device, non_blocking=True)
 
 
