@@ -1411,10 +1411,15 @@ int launch_gemm_tv(GemmArgs& g, const Segs& S, hipStream_t s, int* nblk_out) {
     const dim3 grid = EPI == EPI_SLAB ? dim3(pn2::ceil_div(g.M, TILE), pn2::ceil_div(g.N, TILE), nblk)
                                       : dim3(nblk, pn2::ceil_div(g.N, TILE), 1);
     if (nblk_out) *nblk_out = nblk;
-    const char* name = BF16 ? (EPI == EPI_FWD ? "gemm_fwd_bf16" : EPI == EPI_STORE ? "gemm_dgrad_bf16" : "gemm_wgrad_bf16")
-                            : (EPI == EPI_FWD ? "gemm_fwd" : EPI == EPI_STORE ? "gemm_dgrad" : "gemm_wgrad");
+    // (the dgrad that closes a pair of linked chains also reads C -- its accumulators start from the sibling's gradient --
+    // and the producing layer's rows for its BatchNorm-backward sums: its own group in the profile, with those bytes)
+    const bool closing = EPI == EPI_STORE && g.accumulate;
+    const char* name = BF16 ? (EPI == EPI_FWD ? "gemm_fwd_bf16" : EPI == EPI_STORE ? (closing ? "gemm_dgrad_acc_bf16" : "gemm_dgrad_bf16")
+                                                                                     : "gemm_wgrad_bf16")
+                            : (EPI == EPI_FWD ? "gemm_fwd" : EPI == EPI_STORE ? (closing ? "gemm_dgrad_acc" : "gemm_dgrad") : "gemm_wgrad");
     const double mk = (double)g.M * g.K * (A_KIND == TR_DY ? 2 : 1), kn = (double)g.K * g.N * (B_KIND == TR_DY ? 2 : 1);
-    const double bytes = 4.0 * (mk + kn + (double)g.M * g.N * (EPI == EPI_SLAB ? nblk : 1));
+    const double extra = (closing ? 1.0 : 0.0) + ((EPI == EPI_STORE && g.partial) ? 1.0 : 0.0);   // C read, ey read
+    const double bytes = 4.0 * (mk + kn + (double)g.M * g.N * ((EPI == EPI_SLAB ? nblk : 1) + extra));
     PN2_LAUNCH(name, bytes, 2.0 * g.M * g.N * g.K, (gemm_kernel<A_T, A_KIND, B_T, B_KIND, EPI, TILE, VEC, TEAMS, BF16>), grid,
                dim3(NT * TEAMS), s, g, st);
     hipError_t e = hipGetLastError();
