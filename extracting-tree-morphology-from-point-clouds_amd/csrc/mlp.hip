@@ -235,6 +235,9 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& g, f32x16 (&a
                                               int lane, int split, long long chunk) {
     const int l31 = lane & 31, half = lane >> 5;
     const int m0 = row0, wm = 0, WT = chunk_rows, n0 = col0, wn = 0;   // names used by the body below
+    // statistics partials: element (chunk, which, col) at chunk * pchunk + which * pwhich + col * pcol --
+    // row-major [chunk][2][N] or channel-major (GemmArgs::pstride)
+    const long long pchunk = g.pstride ? 2 : 2ll * g.N, pcol = g.pstride ? g.pstride : 1, pwhich = g.pstride ? 1 : g.N;
     (void)wm; (void)wn;
     // ---- epilogue.  C/D layout of 32x32x2: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
     float* C = g.C;
@@ -276,12 +279,10 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& g, f32x16 (&a
                 }
             m2 += __shfl_xor(m2, 32, 64);
             if (half == 0 && cok && m0 + wm * WT < g.M) {
-                if (g.pstride) {
-                    *(float2*)(g.partial + (long long)col * g.pstride + chunk * 2) = make_float2(mean, m2);
-                } else {
-                    g.partial[(chunk * 2 + 0) * g.N + col] = mean;
-                    g.partial[(chunk * 2 + 1) * g.N + col] = m2;
-                }
+                // one address formula for both layouts (a branch here costs the dgrad kernel 50 us: measured)
+                float* pp = g.partial + chunk * pchunk + (long long)col * pcol;
+                pp[0] = mean;
+                pp[pwhich] = m2;
             }
         }
         if (EPI == EPI_STORE && g.partial) {
@@ -305,12 +306,9 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& g, f32x16 (&a
             s1 += __shfl_xor(s1, 32, 64);
             s2 += __shfl_xor(s2, 32, 64);
             if (half == 0 && cok && m0 + wm * WT < g.M) {
-                if (g.pstride) {
-                    *(float2*)(g.partial + (long long)col * g.pstride + chunk * 2) = make_float2(s1, s2);
-                } else {
-                    g.partial[(chunk * 2 + 0) * g.N + col] = s1;
-                    g.partial[(chunk * 2 + 1) * g.N + col] = s2;
-                }
+                float* pp = g.partial + chunk * pchunk + (long long)col * pcol;
+                pp[0] = s1;
+                pp[pwhich] = s2;
             }
         }
     }
@@ -333,7 +331,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[N
 // the fp32 LDS image into the matrix core and multiplied by v_mfma_f32_32x32x16_bf16 -- one instruction per K-tile and
 // accumulator instead of eight fp32 ones, fp32 accumulation, everything else (staging, transforms, epilogues, what is
 // stored in HBM) unchanged.  The contraction then costs 1/8 of the matrix-pipe time and the kernel is bound by HBM.
-template <bool A_T, int A_KIND, bool B_T, int B_KIND, int EPI, int TILE, bool VEC, int TEAMS, bool BF16 = false>
+// ACC (EPI_STORE only): the accumulators start from C (GemmArgs::accumulate) -- a variant of its own: even a never-taken
+// branch around those 64 loads costs every other dgrad launch ~10 us.
+template <bool A_T, int A_KIND, bool B_T, int B_KIND, int EPI, int TILE, bool VEC, int TEAMS, bool BF16 = false, bool ACC = false>
 __global__ __launch_bounds__(NT * TEAMS, (TEAMS > 1 ? 1 : (EPI == EPI_STORE ? 2 : 3))) void gemm_kernel(const GemmArgs g0,
                                                                                                          const SegTable st) {
     constexpr int LD = TILE + 4, WT = TILE / 2, NI = WT / 32;
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(NT * TEAMS, (TEAMS > 1 ? 1 : (EPI == EPI_STORE ? 2 
         for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    if (EPI == EPI_STORE && team == 0 && g.accumulate) {   // uniform per wavefront; the other teams add their partial tiles later
+    if (ACC && EPI == EPI_STORE && team == 0) {   // uniform per wavefront; the other teams add their partial tiles later
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -1420,8 +1420,12 @@ int launch_gemm_tv(GemmArgs& g, const Segs& S, hipStream_t s, int* nblk_out) {
     const double mk = (double)g.M * g.K * (A_KIND == TR_DY ? 2 : 1), kn = (double)g.K * g.N * (B_KIND == TR_DY ? 2 : 1);
     const double extra = (closing ? 1.0 : 0.0) + ((EPI == EPI_STORE && g.partial) ? 1.0 : 0.0);   // C read, ey read
     const double bytes = 4.0 * (mk + kn + (double)g.M * g.N * ((EPI == EPI_SLAB ? nblk : 1) + extra));
-    PN2_LAUNCH(name, bytes, 2.0 * g.M * g.N * g.K, (gemm_kernel<A_T, A_KIND, B_T, B_KIND, EPI, TILE, VEC, TEAMS, BF16>), grid,
-               dim3(NT * TEAMS), s, g, st);
+    if (closing)
+        PN2_LAUNCH(name, bytes, 2.0 * g.M * g.N * g.K, (gemm_kernel<A_T, A_KIND, B_T, B_KIND, EPI, TILE, VEC, TEAMS, BF16, EPI == EPI_STORE>),
+                   grid, dim3(NT * TEAMS), s, g, st);
+    else
+        PN2_LAUNCH(name, bytes, 2.0 * g.M * g.N * g.K, (gemm_kernel<A_T, A_KIND, B_T, B_KIND, EPI, TILE, VEC, TEAMS, BF16>), grid,
+                   dim3(NT * TEAMS), s, g, st);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
