@@ -87,6 +87,30 @@ __device__ __forceinline__ void st_granule(u64* p, u64 v) {
 // round trip of the (fire-and-forget) result stores of the step, which costs more than the step itself.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+__device__ __forceinline__ u64 fps_key(float d, int n) {
+    return d < 0.0f ? 0ull : (((u64)__float_as_uint(d)) << 32) | (u64)(0xFFFFFFFFu - (unsigned)n);
+}
+// wavefront max of a 64-bit key and the lane that holds it; the low word is only reduced when the high words tie
+__device__ __forceinline__ u64 wave_max_key_owner(u64 k, int& owner) {
+    const unsigned hi = (unsigned)(k >> 32), lo = (unsigned)k;
+    const unsigned mh = pn2::wave_max_u32(hi);
+    u64 who = __ballot(hi == mh);
+    unsigned ml;
+    if (__popcll(who) == 1) {
+        owner = (int)__builtin_ctzll(who);
+        ml = (unsigned)__builtin_amdgcn_readlane((int)lo, owner);
+    } else {
+        ml = pn2::wave_max_u32(hi == mh ? lo : 0u);
+        who = __ballot(hi == mh && lo == ml);
+        owner = (int)__builtin_ctzll(who);
+    }
+    return ((u64)mh << 32) | ml;
+}
+__device__ __forceinline__ u64 wave_max_key_only(u64 k) {
+    int owner;
+    return wave_max_key_owner(k, owner);
+}
+
 // GROUPED = false: one workgroup per cloud (G == 1) -- the exchange code is not even compiled in, the loop stays tight.
 // RAGGED: per-cloud offsets (whole-tree batches, G == 1 only); compiled separately so that the regular kernels keep
 // wave-uniform (scalar) cloud sizes and strides.
@@ -181,11 +205,12 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
             const int bestn = base + bestj * T;
             const u64 mykey =
                 bestd < 0.0f ? 0ull : (((u64)__float_as_uint(bestd)) << 32) | (u64)(0xFFFFFFFFu - (unsigned)bestn);
-            const u64 wkey = pn2::wave_max_key((unsigned)(mykey >> 32), (unsigned)mykey);
+            // one reduction of the distance words; the index words only when two lanes share the largest distance
+            int owner;
+            const u64 wkey = wave_max_key_owner(mykey, owner);
             const int buf = i & 1;
             // the lane that owns the wave maximum (keys are unique unless all are 0) publishes key + coordinates
-            const u64 owners = __ballot(mykey == wkey);
-            if (lane == (int)__builtin_ctzll(owners)) {
+            if (lane == owner) {
                 s_key[buf][wave] = wkey;
                 s_xyz[buf][wave][0] = bx;
                 s_xyz[buf][wave][1] = by;
@@ -670,30 +695,6 @@ __global__ __launch_bounds__(kXT) void fps_xcd_kernel(const float* __restrict__ 
 // (The largest keys sit in different unsampled regions and points are dealt to workgroups by index, so they rarely
 // share a workgroup: 368 rounds instead of the ideal 352 on the 262144-point tree.)
 constexpr int kMK = 4;  // samples accepted per round, at most
-
-__device__ __forceinline__ u64 fps_key(float d, int n) {
-    return d < 0.0f ? 0ull : (((u64)__float_as_uint(d)) << 32) | (u64)(0xFFFFFFFFu - (unsigned)n);
-}
-// wavefront max of a 64-bit key and the lane that holds it; the low word is only reduced when the high words tie
-__device__ __forceinline__ u64 wave_max_key_owner(u64 k, int& owner) {
-    const unsigned hi = (unsigned)(k >> 32), lo = (unsigned)k;
-    const unsigned mh = pn2::wave_max_u32(hi);
-    u64 who = __ballot(hi == mh);
-    unsigned ml;
-    if (__popcll(who) == 1) {
-        owner = (int)__builtin_ctzll(who);
-        ml = (unsigned)__builtin_amdgcn_readlane((int)lo, owner);
-    } else {
-        ml = pn2::wave_max_u32(hi == mh ? lo : 0u);
-        who = __ballot(hi == mh && lo == ml);
-        owner = (int)__builtin_ctzll(who);
-    }
-    return ((u64)mh << 32) | ml;
-}
-__device__ __forceinline__ u64 wave_max_key_only(u64 k) {
-    int owner;
-    return wave_max_key_owner(k, owner);
-}
 
 template <int PPT>
 __global__ __launch_bounds__(kXT) void fps_multi_kernel(const float* __restrict__ xyz, int64_t sb, int64_t sn, int64_t sc,
