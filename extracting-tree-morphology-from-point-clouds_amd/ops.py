@@ -75,17 +75,39 @@ def square_distance(src, dst):
     return out
 
 
-# The cell order the last ordered FPS call left in its workspace (include/pn2_hip.h: pn2_fps_order_offset), by the identity of
-# the cloud tensor it sampled.  three_nn schedules its dense points with it when it is handed the same tensor (set
-# abstraction level 1 and feature propagation level 1 both see the level-0 cloud).  Only ever a permutation: a stale entry
-# (another cloud at the same address) costs locality, never a result.  One entry: the view keeps a 3 MB workspace alive.
-_spatial_order = {}
-_cell_index = {}          # same key -> (box, first sorted position of every cell): ball_query searches by cell with them
+# The cell structure the last ordered FPS call left in its workspace (include/pn2_hip.h: pn2_fps_*_offset), remembered for the
+# cloud tensor it sampled: three_nn walks its dense points in that cell order and ball_query searches the cells when they are
+# handed the SAME cloud (set abstraction level 1 and feature propagation level 1 both see the level-0 cloud).
+# "The same cloud" must be airtight -- a ball query over another cloud's cells is simply wrong --, so an entry holds a strong
+# reference to the cloud's STORAGE (the allocator cannot give that memory to another tensor while the entry lives: equal
+# data_ptr / shape / strides then means a view of the very same storage) and the storage's version counter (an in-place
+# write to the cloud bumps it).  One entry: it keeps a workspace (~8 MB at 262144 points) and one cloud alive.
+class _CloudMemo:
+    def __init__(self):
+        self.key = self.storage = self.version = self.order = self.cells = None
+
+    @staticmethod
+    def _key(xyz):
+        return (xyz.data_ptr(), tuple(xyz.shape), tuple(xyz.stride()), xyz.device.index)
+
+    def remember(self, xyz, order, cells):
+        self.key, self.storage, self.version = self._key(xyz), xyz.untyped_storage(), xyz._version
+        self.order, self.cells = order, cells
+
+    def lookup(self, xyz):
+        """-> (order, cells) or (None, None)"""
+        if self.key is None or self._key(xyz) != self.key or xyz._version != self.version:
+            return None, None
+        if xyz.untyped_storage().data_ptr() != self.storage.data_ptr():
+            return None, None
+        return self.order, self.cells
+
+    def clear(self):
+        self.__init__()
+
+
+_cloud_memo = _CloudMemo()
 _NO_ORDER = ctypes.c_size_t(-1).value
-
-
-def _cloud_key(xyz):
-    return (xyz.data_ptr(), tuple(xyz.shape), tuple(xyz.stride()), xyz.device.index)
 
 
 def furthest_point_sample(xyz, npoint, start):
@@ -106,13 +128,11 @@ def furthest_point_sample(xyz, npoint, start):
               _hip.stream_ptr(), nbytes=B * (12 * N + 8 * npoint))
     off = lib.pn2_fps_order_offset(B, N, npoint)
     if off != _NO_ORDER and not os.environ.get("PN2_FPS_NO_SORT"):
-        _spatial_order.clear()
-        _spatial_order[_cloud_key(xyz)] = ws[off:off + 4 * B * N].view(torch.int32).view(B, N)
         boff, coff = lib.pn2_fps_box_offset(B, N, npoint), lib.pn2_fps_cellstart_offset(B, N, npoint)
-        _cell_index.clear()
         xoff = lib.pn2_fps_sorted_xyz_offset(B, N, npoint)
-        _cell_index[_cloud_key(xyz)] = (ws[boff:boff + 32 * B].view(torch.int32), ws[coff:coff + 4 * 4097 * B].view(torch.int32),
-                                        ws[xoff:xoff + 12 * B * N].view(torch.float32))
+        _cloud_memo.remember(xyz, ws[off:off + 4 * B * N].view(torch.int32).view(B, N),
+                             (ws[boff:boff + 32 * B].view(torch.int32), ws[coff:coff + 4 * 4097 * B].view(torch.int32),
+                              ws[xoff:xoff + 12 * B * N].view(torch.float32)))
     if _DEBUG:
         check_status(xyz.device)
     return idx, new_xyz
@@ -128,13 +148,13 @@ def ball_query(radius, nsample, xyz, new_xyz):
     lib = _hip.lib()
     out = torch.empty(B, S, keff, dtype=torch.int32, device=xyz.device)
     r2 = ctypes.c_float(float(radius) ** 2).value  # float32(double(radius)**2), pointnet2_utils.py:107
-    key = _cloud_key(xyz)
-    if key in _cell_index and key in _spatial_order and not os.environ.get("PN2_BQ_NO_CELLS"):
+    order, cells = _cloud_memo.lookup(xyz)
+    if cells is not None and not os.environ.get("PN2_BQ_NO_CELLS"):
         # the cloud was just sampled by an ordered FPS call: sparse balls are searched in the cells it left behind
-        box, cellstart, sorted_xyz = _cell_index[key]
+        box, cellstart, sorted_xyz = cells
         _hip.call("query_ball_point", lib.pn2_ball_query_cells_f32, xyz.data_ptr(), *_strides3(xyz), new_xyz.data_ptr(),
                   *_strides3(new_xyz), B, N, S, r2, int(nsample), box.data_ptr(), cellstart.data_ptr(),
-                  _spatial_order[key].data_ptr(), sorted_xyz.data_ptr(), out.data_ptr(), _hip.stream_ptr(),
+                  order.data_ptr(), sorted_xyz.data_ptr(), out.data_ptr(), _hip.stream_ptr(),
                   nbytes=B * (12 * N + 12 * S + 8 * S * keff))
         return out
     ws = _workspace(lib.pn2_ball_query_workspace_bytes(B, N, S, int(nsample)), xyz.device)
@@ -155,7 +175,7 @@ def three_nn(xyz1, xyz2, want_dist=False):
     idx = torch.empty(B, N, 3, dtype=torch.int32, device=xyz1.device)
     w = torch.empty(B, N, 3, dtype=torch.float32, device=xyz1.device)
     dist = torch.empty(B, N, 3, dtype=torch.float32, device=xyz1.device) if want_dist else None
-    order = _spatial_order.get(_cloud_key(xyz1)) if not os.environ.get("PN2_TNN_NO_ORDER") else None
+    order = _cloud_memo.lookup(xyz1)[0] if not os.environ.get("PN2_TNN_NO_ORDER") else None
     _hip.call("three_nn", _hip.lib().pn2_three_nn_f32, xyz1.data_ptr(), *_strides3(xyz1), xyz2.data_ptr(),
               *_strides3(xyz2), B, N, S, idx.data_ptr(), w.data_ptr(), _hip.ptr(dist), _hip.ptr(order), _hip.stream_ptr(),
               nbytes=B * (12 * N + 12 * S + N * 3 * (8 + 4)))

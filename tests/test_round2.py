@@ -601,7 +601,7 @@ def test_three_nn_in_cell_order_matches_oracle(pn2):
     dense = dev(xyz)
     idx, new_xyz = ops.furthest_point_sample(dense, 256, dev(np.array([3, 4])))
     ops.check_status()
-    order = ops._spatial_order.get(ops._cloud_key(dense))
+    order = ops._cloud_memo.lookup(dense)[0]
     assert order is not None and tuple(order.shape) == (2, 20000)
     assert np.array_equal(np.sort(order.cpu().numpy(), axis=1), np.tile(np.arange(20000, dtype=np.int32), (2, 1)))
     gi, gw, gd = ops.three_nn(dense, new_xyz, want_dist=True)
@@ -638,7 +638,7 @@ def test_ball_query_by_cells_matches_oracle(pn2, case):
     dense = dev(xyz)
     idx, new_xyz = ops.furthest_point_sample(dense, S, dev(np.array([1, 2])))
     ops.check_status()
-    assert ops._cloud_key(dense) in ops._cell_index
+    assert ops._cloud_memo.lookup(dense)[1] is not None
     q = new_xyz if case != "strangers" else new_xyz + 0.37
     want = O.query_ball_point(r, K, xyz, q.cpu().numpy())
     got = ops.ball_query(r, K, dense, q)
@@ -732,3 +732,27 @@ def test_linked_chains_equal_materialised_rows(pn2, segments):
     assert torch.equal(res["linked"][0], res["materialised"][0]) and torch.equal(res["linked"][1], res["materialised"][1])
     for g, h in zip([res["linked"][2]] + res["linked"][3], [res["materialised"][2]] + res["materialised"][3]):
         assert float((g - h).norm()) <= 2e-5 * float(h.norm()) + 1e-7, (float((g - h).norm()), float(h.norm()))
+
+
+@pytest.mark.gpu
+def test_cell_structure_is_never_used_for_another_cloud(pn2):
+    """The cell structure an ordered FPS call leaves behind serves ball_query / three_nn only for the very tensor it sampled:
+    not for a cloud of the same shape elsewhere, not after an in-place write to the cloud, not for another cloud that the
+    allocator would otherwise place at the same address (the memo pins the storage)."""
+    from pn2_amd import ops
+    O.build()
+    a = dev(_cloud(1, 20000, seed=41))
+    idx, new_xyz = ops.furthest_point_sample(a, 256, dev(np.array([0])))
+    assert ops._cloud_memo.lookup(a)[1] is not None
+    assert ops._cloud_memo.lookup(a.clone())[1] is None                      # same values, other storage
+    ptr = a.data_ptr()
+    a.mul_(1.5)                                                               # same storage, other values
+    assert ops._cloud_memo.lookup(a)[1] is None
+    want = O.query_ball_point(0.2, 16, a.cpu().numpy(), new_xyz.cpu().numpy())
+    assert np.array_equal(ops.ball_query(0.2, 16, a, new_xyz).cpu().numpy(), want)
+    del a
+    torch.cuda.empty_cache()
+    b = dev(_cloud(1, 20000, seed=42))                                        # would reuse a's address if a's memory were free
+    assert b.data_ptr() != ptr or ops._cloud_memo.lookup(b)[1] is None
+    want = O.query_ball_point(0.2, 16, b.cpu().numpy(), new_xyz.cpu().numpy())
+    assert np.array_equal(ops.ball_query(0.2, 16, b, new_xyz).cpu().numpy(), want)
