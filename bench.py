@@ -307,6 +307,8 @@ def main():
             roofline.update({"bound": "latency", "us_per_sample": 1e6 * avg_s / npoint, "samples": npoint,
                              "note": "hbm figures kept for the contract; the kernel reads its cloud once and is bound by dependent rounds"})
         traffic, source = pmc_traffic(dom["name"])
+        if dom["name"] == "fps":
+            roofline["rounds"] = ops.last_fps_rounds()     # exchanges of the level-1 call (up to 16 samples each)
         roofline["traffic"] = traffic
         roofline["traffic_source"] = (f"{source}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; "
                                       "not re-measured in this run") if source else None

@@ -63,6 +63,7 @@ SIGNATURES = {
     "pn2_square_distance_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _int, _int, _int, _vp, _vp]),
     "pn2_fps_workspace_bytes": (_sz, [_int, _int, _int]),
     "pn2_fps_order_offset": (_sz, [_int, _int, _int]),
+    "pn2_fps_rounds_offset": (_sz, [_int, _int, _int]),
     "pn2_fps_box_offset": (_sz, [_int, _int, _int]),
     "pn2_fps_cellstart_offset": (_sz, [_int, _int, _int]),
     "pn2_fps_sorted_xyz_offset": (_sz, [_int, _int, _int]),

@@ -16,6 +16,7 @@
 // Granules are never reused inside a launch (one slot per (cloud, step, member)), the slot array is zeroed
 // by a memset node ahead of the kernel, every granule carries its own validity (bit 63 of the key granule,
 // the step number in the coordinate granules) and is written by ONE 8-byte store, and every spin is bounded.
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -1250,7 +1251,8 @@ __global__ __launch_bounds__(kXT) void fps_sorted_kernel(const float* __restrict
         const unsigned long long rt0 = __builtin_amdgcn_s_memrealtime(), ct0 = __builtin_amdgcn_s_memtime();
 #endif
 
-        for (int round = 0; count < npoint; ++round) {
+        int rounds_done = 0;
+        for (int round = 0; count < npoint; ++round, ++rounds_done) {
             const int buf = round & 1;
 #ifdef PN2_FPS_DIAG
             tprev = __builtin_amdgcn_s_memtime();
@@ -1474,6 +1476,7 @@ __global__ __launch_bounds__(kXT) void fps_sorted_kernel(const float* __restrict
             }
             count += m;
         }
+        if (tid == 0 && g == 0 && b == 0) hdr->pad[0] = (unsigned)rounds_done;   // exchanges cloud 0 took (pn2_fps_rounds_offset)
 #ifdef PN2_FPS_DIAG
         if (tid == 0 && g == 0 && b == 0) {
             unsigned long long* dbg = (unsigned long long*)((char*)hdr + 64);   // first granule bytes (diag only)
@@ -1626,6 +1629,11 @@ extern "C" size_t pn2_fps_workspace_bytes(int B, int N, int npoint) {
 extern "C" size_t pn2_fps_order_offset(int B, int N, int npoint) {
     if (B <= 0 || N <= 0 || npoint <= 0 || !use_xcd_kernel(N) || !use_multi_pick(N, npoint) || !use_sorted(B, N)) return (size_t)-1;
     return order_layout(xcd_plain_bytes(B, N, npoint), B, N).order;
+}
+// ... the number of exchanges the ordered kernel needed for cloud 0 (uint32, written when the launch ends; profiling aid) ...
+extern "C" size_t pn2_fps_rounds_offset(int B, int N, int npoint) {
+    if (pn2_fps_order_offset(B, N, npoint) == (size_t)-1) return (size_t)-1;
+    return offsetof(XcdHeader, pad);
 }
 // ... and the cell structure behind it: the cloud's box (uint32 [B][8], csrc/pn2_cells.h) and the first sorted position of
 // every cell (int32 [B][4097], Morton-numbered 16 x 16 x 16 cells, last entry N).

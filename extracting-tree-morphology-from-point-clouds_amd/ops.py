@@ -107,6 +107,12 @@ class _CloudMemo:
 
 
 _cloud_memo = _CloudMemo()
+
+
+def last_fps_rounds():
+    """Exchanges (rounds of up to 16 samples) the last ordered FPS call needed for its first cloud, or None; synchronises."""
+    r = getattr(_cloud_memo, "rounds", None)
+    return None if r is None else int(r.item())
 _NO_ORDER = ctypes.c_size_t(-1).value
 
 
@@ -130,6 +136,8 @@ def furthest_point_sample(xyz, npoint, start):
     if off != _NO_ORDER and not os.environ.get("PN2_FPS_NO_SORT"):
         boff, coff = lib.pn2_fps_box_offset(B, N, npoint), lib.pn2_fps_cellstart_offset(B, N, npoint)
         xoff = lib.pn2_fps_sorted_xyz_offset(B, N, npoint)
+        roff = lib.pn2_fps_rounds_offset(B, N, npoint)
+        _cloud_memo.rounds = ws[roff:roff + 4].view(torch.int32)
         _cloud_memo.remember(xyz, ws[off:off + 4 * B * N].view(torch.int32).view(B, N),
                              (ws[boff:boff + 32 * B].view(torch.int32), ws[coff:coff + 4 * 4097 * B].view(torch.int32),
                               ws[xoff:xoff + 12 * B * N].view(torch.float32)))

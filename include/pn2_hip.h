@@ -76,6 +76,7 @@ int pn2_square_distance_f32(const float *src, int64_t ab, int64_t an, int64_t ac
  */
 size_t pn2_fps_workspace_bytes(int B, int N, int npoint);
 size_t pn2_fps_order_offset(int B, int N, int npoint);
+size_t pn2_fps_rounds_offset(int B, int N, int npoint);    /* uint32: exchanges the ordered kernel took for cloud 0 (profiling) */
 size_t pn2_fps_box_offset(int B, int N, int npoint);       /* uint32 [B][8]: the clouds' boxes (order-preserving encodings) */
 size_t pn2_fps_cellstart_offset(int B, int N, int npoint); /* int32 [B][4097]: first sorted position of every cell, then N */
 size_t pn2_fps_sorted_xyz_offset(int B, int N, int npoint); /* float [B][3][N]: x, y, z planes in cell order */
