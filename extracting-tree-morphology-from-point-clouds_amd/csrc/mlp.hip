@@ -622,6 +622,59 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     }
 }
 
+// Small layers (at most 64 partial chunks): one WAVEFRONT per channel, lane = chunk, float64 sums by shuffles -- no LDS, no
+// workgroup barriers (the block-per-channel kernels spend their 5 us on two 8-step barrier reductions over mostly empty
+// threads).  Same formulas as bn_finalize_kernel / bn_bwd_finalize_kernel.
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__global__ __launch_bounds__(256) void bn_finalize_wave_kernel(const float* __restrict__ partial_, int rows, int CH, int C,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                               float eps, float momentum, float* __restrict__ coef, long long cm) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), k = threadIdx.x & 63;
+    if (c >= C) return;
+    const int nchunk = (rows + CH - 1) / CH;
+    const PartialView partial{partial_, C, c, cm};
+    const bool on = k < nchunk;
+    const int n = on ? (rows - k * CH < CH ? rows - k * CH : CH) : 0;
+    const double pm = on ? (double)partial(k, 0) : 0.0, pv = on ? (double)partial(k, 1) : 0.0;
+    const double mean = wave_sum_f64((double)n * pm) / (double)rows;
+    const double d = pm - mean;
+    const double var = wave_sum_f64(pv + (double)n * d * d) / (double)rows;
+    if (k == 0) {
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float gm = gamma ? gamma[c] : 1.0f, bt = beta ? beta[c] : 0.0f;
+        coef[ST_MEAN * C + c] = (float)mean;
+        coef[ST_VAR * C + c] = (float)var;
+        coef[ST_INVSTD * C + c] = invstd;
+        coef[ST_SCALE * C + c] = gm * invstd;
+        coef[ST_BETA * C + c] = bt;
+        if (running_mean) {
+            const double unbiased = rows > 1 ? var * (double)rows / (double)(rows - 1) : var;
+            running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + (double)momentum * mean);
+            running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + (double)momentum * unbiased);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void bn_bwd_finalize_wave_kernel(const float* __restrict__ partial_, int nblk, int rows, int C,
+                                                                   float* __restrict__ coef, float* __restrict__ dgamma,
+                                                                   float* __restrict__ dbeta, long long cm) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), k = threadIdx.x & 63;
+    if (c >= C) return;
+    const PartialView partial{partial_, C, c, cm};
+    const bool on = k < nblk;
+    const double s1 = wave_sum_f64(on ? (double)partial(k, 0) : 0.0), s2 = wave_sum_f64(on ? (double)partial(k, 1) : 0.0);
+    if (k == 0) {
+        coef[ST_A * C + c] = (float)(s1 / (double)rows);
+        coef[ST_B * C + c] = (float)((double)coef[ST_INVSTD * C + c] * s2 / (double)rows);
+        if (dbeta) dbeta[c] += (float)s1;
+        if (dgamma) dgamma[c] += (float)s2;
+    }
+}
+
 // rows of statistics chunk k of segment s: blocks of `cpb` chunks of `crows` rows tile the segment from its first row
 __device__ __forceinline__ int chunk_rows_in_seg(const SegTable& st, int s, int k, int cpb, int crows) {
     const int row0 = st.row_off[s] + (k - st.blk_off[s] * cpb) * crows;
@@ -1559,6 +1612,11 @@ int launch_bn_finalize(const float* partial, const FinScratch& fs, const Segs& S
                        hipStream_t s, long long cm) {
     const int ch = tile / 2;
     if (S.nseg == 1) {
+        if (pn2::ceil_div(rows, ch) <= 64)
+            PN2_LAUNCH("bn_finalize", 8.0 * pn2::ceil_div(rows, ch) * L.cout, 0, bn_finalize_wave_kernel, dim3(pn2::ceil_div(L.cout, 4)),
+                       dim3(256), s, partial, rows, ch, L.cout, L.gamma, L.beta, L.running_mean, L.running_var, L.eps, L.momentum,
+                       L.stats, cm);
+        else
         PN2_LAUNCH("bn_finalize", 8.0 * pn2::ceil_div(rows, ch) * L.cout, 0, bn_finalize_kernel, dim3(L.cout), dim3(256), s,
                    partial, rows, ch, L.cout, L.gamma, L.beta, L.running_mean, L.running_var, L.eps, L.momentum, L.stats, cm);
         PN2_LAUNCH_CHECK();
@@ -1586,6 +1644,10 @@ int launch_bn_bwd_finalize(const float* partial, const FinScratch& fs, const Seg
     int nblk = 0;
     const SegTable st = make_table(S, R, &nblk);
     if (S.nseg == 1) {
+        if (pn2::ceil_div(rows, R / cpb) <= 64)
+            PN2_LAUNCH("bn_bwd_finalize", 8.0 * nblk * cpb * L.cout, 0, bn_bwd_finalize_wave_kernel, dim3(pn2::ceil_div(L.cout, 4)),
+                       dim3(256), s, partial, pn2::ceil_div(rows, R / cpb), rows, L.cout, L.stats, L.dgamma, L.dbeta, cm);
+        else
         PN2_LAUNCH("bn_bwd_finalize", 8.0 * nblk * cpb * L.cout, 0, bn_bwd_finalize_kernel, dim3(L.cout), dim3(256), s, partial,
                    pn2::ceil_div(rows, R / cpb), rows, L.cout, L.stats, L.dgamma, L.dbeta, cm);
         PN2_LAUNCH_CHECK();
