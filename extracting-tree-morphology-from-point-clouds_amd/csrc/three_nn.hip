@@ -320,7 +320,9 @@ __global__ __launch_bounds__(TIG_T) void tig_fill_kernel(const int32_t* __restri
 }
 
 // one wavefront per 64-row chunk of a destination's list; lane l owns channels l and l + 64 of a 128-channel block
-constexpr int TIG_SLOTS = 32;
+// 16 table slots: the table is what limits the wavefronts -- and with them the bytes in flight -- per compute unit (32 slots:
+// 120 us at 262 144 x 1024 x 128, 16: 100 us; scattered neighbours beyond the table go to memory as atomics)
+constexpr int TIG_SLOTS = 16;
 __global__ __launch_bounds__(kBlock) void tig_reduce_kernel(const float* __restrict__ dout, int64_t out_stride, int64_t out_offset,
                                                             const int32_t* __restrict__ idx, const float* __restrict__ w,
                                                             const int* __restrict__ offs, const int* __restrict__ coffs,
