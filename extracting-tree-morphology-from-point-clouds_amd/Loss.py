@@ -11,6 +11,27 @@ from . import _hip
 from .Utils import cuda_cast
 
 
+def mask_ranks(pad, masks_off):
+    """pad [R] bool (real rows of the padded batch), masks_off [n] bool (per REAL row: its offset counts) ->
+    (cum_pad int64 [R], off_mask bool [R], cum_off int64 [R]) -- what
+        cum_pad = cumsum(pad); off_mask = pad & masks_off[(cum_pad - 1).clamp(0, n - 1)]; cum_off = cumsum(off_mask)
+    gives (get_loss, PointNet2.py:188-196), in one launch."""
+    _hip.require_device(pad, masks_off)
+    if pad.dtype != torch.bool or masks_off.dtype != torch.bool:
+        raise RuntimeError("mask_ranks: boolean masks expected")
+    pad, masks_off = pad.contiguous(), masks_off.contiguous()
+    R = pad.numel()
+    if masks_off.numel() == 0:
+        raise RuntimeError("mask_ranks: masks_off is empty")
+    cum_pad = torch.empty(R, dtype=torch.int64, device=pad.device)
+    cum_off = torch.empty(R, dtype=torch.int64, device=pad.device)
+    off_mask = torch.empty(R, dtype=torch.bool, device=pad.device)
+    if R:
+        _hip.call("mask_ranks", _hip.lib().pn2_mask_ranks, pad.data_ptr(), masks_off.data_ptr(), R, masks_off.numel(),
+                  cum_pad.data_ptr(), off_mask.data_ptr(), cum_off.data_ptr(), _hip.stream_ptr())
+    return cum_pad, off_mask, cum_off
+
+
 class MaskedPointLoss(torch.autograd.Function):
     """(sem [R,2], off [R,3], pad, off_mask, cum_pad, cum_off, sem_labels, off_labels) -> tensor [2] =
     (semantic loss, offset loss) of the masked rows; one forward and one backward kernel (csrc/loss.hip)."""

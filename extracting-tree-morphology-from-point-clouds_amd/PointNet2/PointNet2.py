@@ -13,7 +13,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops, streaming
-from ..Loss import MaskedPointLoss, point_wise_loss
+from ..Loss import MaskedPointLoss, mask_ranks, point_wise_loss
 from ..mlp import batched_counters, chain_pair_rows
 from ..Utils import cuda_cast
 from .pointnet2_utils import start_batch
@@ -152,10 +152,14 @@ class PointNet2(nn.Module):
             return self.get_loss_hierarchical({"semantic_prediction_logits": sem_v, "offset_predictions": off_v},
                                               semantic_labels, offset_labels)
         pad = masks_pad.reshape(-1)
-        cum_pad = torch.cumsum(pad, 0)                       # cum - 1 = index of a real row among the real rows
-        off_mask = pad & masks_off.index_select(0, (cum_pad - 1).clamp(0, masks_off.numel() - 1))
-        cum_off = torch.cumsum(off_mask, 0)
-        if sem.is_cuda and semantic_labels.dtype == torch.long:
+        fused = sem.is_cuda and semantic_labels.dtype == torch.long
+        if fused and pad.dtype == torch.bool and masks_off.dtype == torch.bool and masks_off.numel():
+            cum_pad, off_mask, cum_off = mask_ranks(pad, masks_off)
+        else:
+            cum_pad = torch.cumsum(pad, 0)                   # cum - 1 = index of a real row among the real rows
+            off_mask = pad & masks_off.index_select(0, (cum_pad - 1).clamp(0, masks_off.numel() - 1))
+            cum_off = torch.cumsum(off_mask, 0)
+        if fused:
             both = MaskedPointLoss.apply(sem, off, pad, off_mask, cum_pad, cum_off, semantic_labels.reshape(-1), offset_labels)
             # both multipliers in one multiply and the total as one reduction: the scalar arithmetic of the generic path below
             # (two selects, two multiplies, two adds and their backward nodes) is ten launches of a few microseconds each

@@ -52,6 +52,7 @@ def segments_arg(row_off):
 # name -> (restype, argtypes); must list every symbol include/pn2_hip.h declares (tests/test_abi.py checks)
 SIGNATURES = {
     "pn2_version": (_int, []),
+    "pn2_mask_ranks": (_int, [_vp, _vp, ctypes.c_longlong, ctypes.c_longlong, _vp, _vp, _vp, _vp]),
     "pn2_point_loss_workspace_bytes": (_sz, [_int]),
     "pn2_point_loss_fwd_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _int, _vp, _vp, _sz, _vp]),
     "pn2_point_loss_bwd_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _int, _vp, _vp, _vp, _vp]),

@@ -124,6 +124,89 @@ inline int loss_blocks(int R) {
     return b < 1 ? 1 : (b > 1024 ? 1024 : b);
 }
 
+// ---------------------------------------------------------------------------------------------- mask ranks
+// cum_pad, off_mask, cum_off of get_loss (PointNet2.py:188-196: boolean masking of the padded rows, then of the rows whose
+// offsets count) in ONE launch instead of two prefix sums, a gather and the element-wise glue between them.  Workgroup i
+// owns rows [1024 i, 1024 i + 1024); what precedes it is two plain counts -- R_i = real rows before the chunk and, because
+// the real rows consume masks_off in order, O_i = set entries of masks_off[0 : R_i) -- which every workgroup takes for
+// itself from memory the caches hold anyway (<= 2 x R bytes), so there is no carry between workgroups to wait for.
+constexpr int kRankBlock = 1024;
+
+__device__ __forceinline__ int nonzero_bytes(unsigned x) {
+    return __popc((x | ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu)) & 0x80808080u);
+}
+
+// number of non-zero bytes of m[0 : n), counted by the whole workgroup; `red` = 16 ints of LDS
+__device__ __forceinline__ long long count_prefix(const unsigned char* __restrict__ m, long long n, int* red) {
+    const int t = threadIdx.x;
+    long long c = 0;
+    long long head = (16 - ((uintptr_t)m & 15)) & 15;
+    if (head > n) head = n;
+    if (t < head) c += m[t] != 0;
+    const uint4* v = (const uint4*)(m + head);
+    const long long nv = (n - head) / 16;
+    for (long long e0 = t; e0 < nv; e0 += 8 * kRankBlock) {   // eight loads in flight per thread
+        uint4 q[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const long long e = e0 + (long long)u * kRankBlock;
+            q[u] = v[e < nv ? e : nv - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (e0 + (long long)u * kRankBlock < nv)
+                c += nonzero_bytes(q[u].x) + nonzero_bytes(q[u].y) + nonzero_bytes(q[u].z) + nonzero_bytes(q[u].w);
+    }
+    const long long tail = head + nv * 16;
+    if (tail + t < n) c += m[tail + t] != 0;   // < 16 bytes
+    int w = (int)c;   // <= 16 * ceil(n / 16384) + 2 per thread (n <= 2^30)
+    for (int o = 32; o; o >>= 1) w += __shfl_xor(w, o);
+    __syncthreads();   // red may still be read from the previous use
+    if ((t & 63) == 0) red[t >> 6] = w;
+    __syncthreads();
+    long long total = 0;
+    for (int k = 0; k < kRankBlock / 64; ++k) total += red[k];
+    return total;
+}
+
+// inclusive scan of one flag per thread over the workgroup
+__device__ __forceinline__ int block_scan_flag(bool f, int* red) {
+    const int t = threadIdx.x, lane = t & 63;
+    const unsigned long long b = __ballot(f);
+    const int incl = __popcll(b & (lane == 63 ? ~0ull : ((1ull << (lane + 1)) - 1ull)));
+    __syncthreads();
+    if (lane == 0) red[t >> 6] = __popcll(b);
+    __syncthreads();
+    int before = 0;
+    for (int k = 0; k < (t >> 6); ++k) before += red[k];
+    return before + incl;
+}
+
+__global__ __launch_bounds__(kRankBlock) void mask_ranks_kernel(const unsigned char* __restrict__ pad,
+                                                               const unsigned char* __restrict__ masks_off, long long R,
+                                                               long long n_mask, int64_t* __restrict__ cum_pad,
+                                                               unsigned char* __restrict__ off_mask, int64_t* __restrict__ cum_off) {
+    __shared__ int red[kRankBlock / 64];
+    const long long r0 = (long long)blockIdx.x * kRankBlock, r = r0 + threadIdx.x;
+    const long long real_before = count_prefix(pad, r0, red);
+    // rows beyond n_mask (a masks_off shorter than the number of real rows) all read its last entry, like the clamp of the
+    // torch expression this replaces
+    const long long in_range = real_before < n_mask ? real_before : n_mask;
+    long long off_before = count_prefix(masks_off, in_range, red);
+    if (real_before > n_mask && masks_off[n_mask - 1] != 0) off_before += real_before - n_mask;
+    const bool p = r < R && pad[r] != 0;
+    const long long cp = real_before + block_scan_flag(p, red);
+    long long rank = cp - 1;
+    rank = rank < 0 ? 0 : (rank >= n_mask ? n_mask - 1 : rank);
+    const bool o = p && masks_off[rank] != 0;
+    const long long co = off_before + block_scan_flag(o, red);
+    if (r < R) {
+        cum_pad[r] = cp;
+        off_mask[r] = o ? 1 : 0;
+        cum_off[r] = co;
+    }
+}
+
 }  // namespace
 
 extern "C" size_t pn2_point_loss_workspace_bytes(int R) { return R > 0 ? (size_t)loss_blocks(R) * 2 * sizeof(double) : 0; }
@@ -157,6 +240,17 @@ extern "C" int pn2_point_loss_bwd_f32(const float* sem, const float* off, const 
     PN2_LAUNCH("point_loss_bwd", 58.0 * R, 0, point_loss_bwd_kernel, dim3(loss_blocks(R)), dim3(kBlock), (hipStream_t)stream, sem,
                off, (const bool*)pad, (const bool*)off_mask, cum_pad, cum_off, sem_labels, (long long)n_sem, off_labels,
                (long long)n_off, R, grad2, dsem, doff);
+    PN2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pn2_mask_ranks(const unsigned char* pad, const unsigned char* masks_off, long long R, long long n_mask,
+                              int64_t* cum_pad, unsigned char* off_mask, int64_t* cum_off, void* stream) {
+    if (!pad || !masks_off || !cum_pad || !off_mask || !cum_off || R <= 0 || n_mask <= 0 || R > (1LL << 30)) return PN2_E_BADARG;
+    const long long blocks = (R + kRankBlock - 1) / kRankBlock;
+    if (blocks > 0x7FFFFFFFLL) return PN2_E_BADARG;
+    PN2_LAUNCH("mask_ranks", 18.0 * R, 0, mask_ranks_kernel, dim3((unsigned)blocks), dim3(kRankBlock), (hipStream_t)stream, pad,
+               masks_off, R, n_mask, cum_pad, off_mask, cum_off);
     PN2_LAUNCH_CHECK();
     return 0;
 }

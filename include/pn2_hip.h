@@ -149,6 +149,11 @@ int pn2_three_nn_f32(const float *xyz1, int64_t ab, int64_t an, int64_t ac, cons
  *   [n_sem] int64, off_labels [n_off,3]).  out2 = {sum_pad CE / max(n_valid,1), sum_offmask sqrt(max(|d|^2,1e-8)) /
  *   max(n_off_rows,1)}.  Backward: grad2 = d/d out2 -> dsem [R,2], doff [R,3] (zero on masked-out rows).
  */
+/* The masks' prefix sums get_loss needs (PointNet2.py:188-196), one launch: cum_pad[r] = inclusive count of pad[0..r],
+ * off_mask[r] = pad[r] && masks_off[clamp(cum_pad[r] - 1, 0, n_mask - 1)], cum_off[r] = inclusive count of off_mask.
+ * pad [R], masks_off [n_mask] are torch.bool storage (one byte per element, non-zero = true). */
+int pn2_mask_ranks(const unsigned char *pad, const unsigned char *masks_off, long long R, long long n_mask,
+                   int64_t *cum_pad, unsigned char *off_mask, int64_t *cum_off, void *stream);
 size_t pn2_point_loss_workspace_bytes(int R);
 int pn2_point_loss_fwd_f32(const float *sem, const float *off, const unsigned char *pad, const unsigned char *off_mask,
                            const int64_t *cum_pad, const int64_t *cum_off, const int64_t *sem_labels, int64_t n_sem,

@@ -756,3 +756,39 @@ def test_cell_structure_is_never_used_for_another_cloud(pn2):
     assert b.data_ptr() != ptr or ops._cloud_memo.lookup(b)[1] is None
     want = O.query_ball_point(0.2, 16, b.cpu().numpy(), new_xyz.cpu().numpy())
     assert np.array_equal(ops.ball_query(0.2, 16, b, new_xyz).cpu().numpy(), want)
+
+
+@pytest.mark.gpu
+def test_mask_ranks_equal_the_torch_expressions(pn2):
+    """get_loss's mask arithmetic (two prefix sums + a gather, PointNet2.py:188-196) as one launch: integer work, so equal
+    -- for ragged sizes, unaligned views, all-true / all-false masks, non-0/1 true bytes, and a masks_off that is shorter
+    than the number of real rows (the torch expression clamps)."""
+    from pn2_amd.Loss import mask_ranks
+    g = torch.Generator(device="cpu").manual_seed(5)
+
+    def check(pad, moff):
+        cum_pad = torch.cumsum(pad, 0)
+        off_mask = pad & moff.index_select(0, (cum_pad - 1).clamp(0, moff.numel() - 1))
+        cum_off = torch.cumsum(off_mask, 0)
+        a, b, c = mask_ranks(pad, moff)
+        assert a.dtype == torch.int64 and b.dtype == torch.bool and c.dtype == torch.int64
+        assert torch.equal(a, cum_pad) and torch.equal(b, off_mask) and torch.equal(c, cum_off)
+
+    for R, p_pad, p_off in [(262144, 0.8, 0.5), (1, 1.0, 1.0), (1023, 0.5, 0.5), (1025, 0.5, 0.9), (70001, 0.3, 0.1),
+                            (40000, 1.0, 1.0), (40000, 0.0, 0.5), (300000, 0.97, 0.0)]:
+        pad = (torch.rand(R, generator=g) < p_pad).cuda()
+        n_real = max(int(pad.sum().item()), 1)
+        moff = (torch.rand(n_real, generator=g) < p_off).cuda()
+        check(pad, moff)
+        if n_real > 10:
+            check(pad, moff[: n_real // 2])          # too short: clamped to its last entry
+            check(pad, moff[: n_real // 2 - 1])
+    # views at odd byte offsets, and "true" stored as another non-zero byte
+    base = (torch.rand(100000, generator=g) < 0.6).cuda()
+    mo = (torch.rand(100000, generator=g) < 0.4).cuda()
+    check(base[3:90001], mo[5:])
+    raw = (base.view(torch.uint8) * 255).view(torch.bool)
+    a, _, _ = mask_ranks(raw, mo)
+    assert torch.equal(a, torch.cumsum(base, 0))
+    with pytest.raises(RuntimeError):
+        mask_ranks(base, mo[:0])
