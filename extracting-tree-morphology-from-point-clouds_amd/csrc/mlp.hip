@@ -970,6 +970,57 @@ __global__ __launch_bounds__(256) void maxpool_scatter_kernel(const float* __res
     }
 }
 
+// The same scatter for a pooled layer that ends in a BatchNorm, with that BatchNorm's backward column sums taken on the
+// way: only the arg-max row of a group carries a gradient, so the sums need (dout, arg, Y at the arg-max rows) -- S x C
+// elements instead of a second pass over the K times larger (dz, Y).  One workgroup per R rows (whole groups: K divides
+// R <= PS_ROWS; the host picks R so that even the deep levels give every compute unit a block),
+// partial[blk][0 / 1][c] like bn_bwd_reduce_kernel.
+constexpr int PS_ROWS = 256;
+__global__ __launch_bounds__(256) void maxpool_scatter_sums_kernel(const float* __restrict__ dout, const int32_t* __restrict__ arg,
+                                                                   int K, int C, int R, const float* __restrict__ y,
+                                                                   const float* __restrict__ coef, int relu,
+                                                                   float* __restrict__ dz, float* __restrict__ partial,
+                                                                   const SegTable st) {
+    __shared__ float red[2][256];
+    const RowBlock rb = row_block(st, (int)blockIdx.x, R);
+    const int r0 = rb.row0, r1 = r0 + R < rb.row_end ? r0 + R : rb.row_end;
+    coef += (long long)rb.seg * ST_ROWS * C;
+    const int g0 = r0 / K, g1 = r1 / K;   // segments and row blocks hold whole groups
+    const int cw = C >= 256 ? 256 : (C > 128 ? 256 : C > 64 ? 128 : 64);
+    const int ng = 256 / cw;              // groups worked on in parallel
+    const int tc = threadIdx.x % cw, tg = threadIdx.x / cw;
+    for (int c0 = 0; c0 < C; c0 += cw) {
+        const int c = c0 + tc;
+        float s1 = 0.f, s2 = 0.f;
+        if (c < C) {
+            const float mean = coef[ST_MEAN * C + c], sc = coef[ST_SCALE * C + c], bt = coef[ST_BETA * C + c],
+                        is = coef[ST_INVSTD * C + c];
+            for (int gi = g0 + tg; gi < g1; gi += ng) {
+                const int ka = arg[(long long)gi * C + c];
+                const float g = dout[(long long)gi * C + c];
+                const long long base = (long long)gi * K;
+                if ((unsigned)ka < (unsigned)K) {
+                    const float yy = y[(base + ka) * C + c];
+                    const float t = __builtin_fmaf(yy - mean, sc, bt);
+                    const float gz = (!relu || t > 0.f) ? g : 0.f;
+                    s1 += gz;
+                    s2 += gz * ((yy - mean) * is);
+                }
+                for (int k = 0; k < K; ++k) dz[(base + k) * C + c] = k == ka ? g : 0.0f;
+            }
+        }
+        red[0][threadIdx.x] = s1;
+        red[1][threadIdx.x] = s2;
+        __syncthreads();
+        if (tg == 0 && c < C) {
+            for (int q = 1; q < ng; ++q) s1 += red[0][q * cw + tc], s2 += red[1][q * cw + tc];
+            partial[((long long)blockIdx.x * 2 + 0) * C + c] = s1;
+            partial[((long long)blockIdx.x * 2 + 1) * C + c] = s2;
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------ BatchNorm: backward
 // partial[blk][0][c] = sum_r dzhat, partial[blk][1][c] = sum_r dzhat * xhat over the block's RB rows.
 // Each thread owns 4 consecutive channels (16-byte loads of dz and y), row groups are combined through LDS.
@@ -1821,18 +1872,35 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
     long long lddz = layers[nlayers - 1].cout;
     float* bufs[2] = {scratch_a, scratch_b};
     int which = 0;
+    int pooled_R = 0;   // > 0: the max-pool scatter left the pooled layer's BatchNorm-backward sums, row blocks of this size
     if (pool_k > 1) {
         if (!pool_arg) return PN2_E_BADARG;
-        const int C = layers[nlayers - 1].cout;
-        PN2_LAUNCH("maxpool_scatter", 4.0 * rows * C + 8.0 * (rows / pool_k) * C, 0, maxpool_scatter_kernel,
-                   dim3(grid1d((long long)rows * C)), dim3(256), s, dout, pool_arg, (long long)(rows / pool_k), pool_k, C,
-                   bufs[which]);
+        const pn2_mlp_layer& PL = layers[nlayers - 1];
+        const int C = PL.cout;
+        const bool no_sums = getenv("PN2_POOL_NO_SUMS") != nullptr;   // tests: the two-pass path
+        if (PL.has_bn && PL.y && PL.stats && pool_k <= PS_ROWS && !no_sums) {
+            // the BatchNorm-backward sums of the pooled layer come out of the scatter (no bn_bwd_reduce pass); row blocks
+            // of whole groups, as many as keep ~256 workgroups busy
+            int gpb = (rows / pool_k) / 256;
+            if (gpb > PS_ROWS / pool_k) gpb = PS_ROWS / pool_k;
+            if (gpb * pool_k < 32) gpb = pn2::ceil_div(32, pool_k);   // the partial buffer is sized for chunks of >= 32 rows
+            pooled_R = gpb * pool_k;
+            int nblk = 0;
+            const SegTable tb = make_table(S, pooled_R, &nblk);
+            PN2_LAUNCH("maxpool_scatter", 4.0 * rows * C + 16.0 * (rows / pool_k) * C, 0, maxpool_scatter_sums_kernel, dim3(nblk),
+                       dim3(256), s, dout, pool_arg, pool_k, C, pooled_R, (const float*)PL.y, (const float*)PL.stats, PL.relu,
+                       bufs[which], ws, tb);
+        } else {
+            PN2_LAUNCH("maxpool_scatter", 4.0 * rows * C + 8.0 * (rows / pool_k) * C, 0, maxpool_scatter_kernel,
+                       dim3(grid1d((long long)rows * C)), dim3(256), s, dout, pool_arg, (long long)(rows / pool_k), pool_k, C,
+                       bufs[which]);
+        }
         PN2_LAUNCH_CHECK();
         dz = bufs[which];
         which ^= 1;
     }
     // BatchNorm-backward partials of the current layer already in ws?  (R, cpb): row-block size and chunks per block
-    int fused_R = 0, fused_cpb = 0;
+    int fused_R = pooled_R, fused_cpb = pooled_R ? 1 : 0;
     long long fused_cm = 0;   // layout of those partials (cm_stride)
     for (int i = nlayers - 1; i >= 0; --i) {
         const pn2_mlp_layer& L = layers[i];

@@ -63,6 +63,8 @@ def rel(a, b):
     (32 * 100, 7, [32, 32, 64], 32, True, nn.Conv2d, nn.BatchNorm2d),        # SA1-like, unaligned cin
     (32 * 37, 67, [64, 64, 128], 32, True, nn.Conv2d, nn.BatchNorm2d),       # ragged rows, cin = 64 + 3
     (16 * 8, 259, [256, 256, 512], 16, True, nn.Conv2d, nn.BatchNorm2d),     # wide, multi-tile N and K
+    (32 * 1024, 7, [32, 32, 64], 32, True, nn.Conv2d, nn.BatchNorm2d),       # SA1 of the depth-4 table: 128 scatter blocks
+    (20 * 53, 67, [64, 64, 128], 20, True, nn.Conv2d, nn.BatchNorm2d),       # K = min(nsample, N) when a cloud is small
     (5000, 128, [128, 128, 128], 1, True, nn.Conv1d, nn.BatchNorm1d),        # FP1-like
     (3001, 128, [128, 3], 1, False, nn.Conv1d, nn.BatchNorm1d),              # ConvHead: last conv bare, cout = 3
     (777, 320, [256, 128], 1, True, nn.Conv1d, nn.BatchNorm1d),              # FP2-like
@@ -97,6 +99,14 @@ def test_chain_forward_backward(chain_rows, rows, cin, widths, pool_k, last_bn, 
             assert float(c_.bias.grad.abs().max()) == 0.0           # analytically zero, kept exactly zero
         else:
             assert rel(c_.bias.grad.cpu().double(), b.grad) < 1e-4, "dbias"
+
+
+def test_pooled_chain_two_pass_sums(chain_rows, monkeypatch):
+    """The pooled layer's BatchNorm-backward sums come out of the max-pool scatter by default; PN2_POOL_NO_SUMS=1 takes the
+    scatter + bn_bwd_reduce pair instead: both against the float64 reference."""
+    monkeypatch.setenv("PN2_POOL_NO_SUMS", "1")
+    test_chain_forward_backward(chain_rows, 32 * 100, 7, [32, 32, 64], 32, True, nn.Conv2d, nn.BatchNorm2d)
+    test_chain_forward_backward(chain_rows, 16 * 8, 259, [256, 256, 512], 16, True, nn.Conv2d, nn.BatchNorm2d)
 
 
 def test_running_stats_and_eval_mode(chain_rows):
