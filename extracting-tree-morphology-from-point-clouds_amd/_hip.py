@@ -113,6 +113,7 @@ ABI_VERSION = 3                      # PN2_ABI_VERSION of include/pn2_hip.h
 CHAIN_ACCUMULATE_DX = 0x100          # PN2_CHAIN_ACCUMULATE_DX
 CHAIN_DEFER_WGRAD = 0x200            # PN2_CHAIN_DEFER_WGRAD
 CHAIN_LAZY_OUT = 0x400               # PN2_CHAIN_LAZY_OUT
+CHAIN_ZERO_LEAD = 0x800              # PN2_CHAIN_ZERO_LEAD
 STATUS_FPS_HANDOFF, STATUS_FPS_ARRIVAL, STATUS_BAD_INDEX = 1, 2, 4   # PN2_STATUS_* bits
 
 

@@ -980,10 +980,13 @@ __global__ __launch_bounds__(256) void maxpool_scatter_sums_kernel(const float* 
                                                                    int K, int C, int R, const float* __restrict__ y,
                                                                    const float* __restrict__ coef, int relu,
                                                                    float* __restrict__ dz, float* __restrict__ partial,
-                                                                   const SegTable st) {
+                                                                   const SegTable st, float* __restrict__ lead, long long ldlead,
+                                                                   int nlead) {
     __shared__ float red[2][256];
     const RowBlock rb = row_block(st, (int)blockIdx.x, R);
     const int r0 = rb.row0, r1 = r0 + R < rb.row_end ? r0 + R : rb.row_end;
+    // PN2_CHAIN_ZERO_LEAD: the block's rows of the chain's input gradient, columns [0, nlead)
+    for (int e = threadIdx.x; e < (r1 - r0) * nlead; e += 256) lead[(long long)(r0 + e / nlead) * ldlead + e % nlead] = 0.0f;
     coef += (long long)rb.seg * ST_ROWS * C;
     const int g0 = r0 / K, g1 = r1 / K;   // segments and row blocks hold whole groups
     const int cw = C >= 256 ? 256 : (C > 128 ? 256 : C > 64 ? 128 : 64);
@@ -1019,6 +1022,11 @@ __global__ __launch_bounds__(256) void maxpool_scatter_sums_kernel(const float* 
         }
         __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(256) void zero_lead_kernel(float* __restrict__ lead, long long ldlead, int nlead, long long total) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256)
+        lead[(e / nlead) * ldlead + e % nlead] = 0.0f;
 }
 
 // ------------------------------------------------------------------------------------------ BatchNorm: backward
@@ -1855,7 +1863,9 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
     if (dx_first_col < 0 || dx_first_col >= layers[0].cin) return PN2_E_BADARG;
     const int accumulate_dx = (precision & PN2_CHAIN_ACCUMULATE_DX) ? 1 : 0;
     const bool defer_wgrad = (precision & PN2_CHAIN_DEFER_WGRAD) != 0;
-    precision &= ~(PN2_CHAIN_ACCUMULATE_DX | PN2_CHAIN_DEFER_WGRAD);
+    bool zero_lead = (precision & PN2_CHAIN_ZERO_LEAD) != 0 && dx && dx_first_col > 0;
+    if (zero_lead && accumulate_dx) return PN2_E_BADARG;
+    precision &= ~(PN2_CHAIN_ACCUMULATE_DX | PN2_CHAIN_DEFER_WGRAD | PN2_CHAIN_ZERO_LEAD);
     if (precision != PN2_PRECISION_F32 && precision != PN2_PRECISION_BF16) return PN2_E_BADARG;
     if (accumulate_dx && !dx) return PN2_E_BADARG;
     t_precision = precision;
@@ -1889,7 +1899,8 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
             const SegTable tb = make_table(S, pooled_R, &nblk);
             PN2_LAUNCH("maxpool_scatter", 4.0 * rows * C + 16.0 * (rows / pool_k) * C, 0, maxpool_scatter_sums_kernel, dim3(nblk),
                        dim3(256), s, dout, pool_arg, pool_k, C, pooled_R, (const float*)PL.y, (const float*)PL.stats, PL.relu,
-                       bufs[which], ws, tb);
+                       bufs[which], ws, tb, zero_lead ? dx : nullptr, (long long)lddx, zero_lead ? dx_first_col : 0);
+            zero_lead = false;
         } else {
             PN2_LAUNCH("maxpool_scatter", 4.0 * rows * C + 8.0 * (rows / pool_k) * C, 0, maxpool_scatter_kernel,
                        dim3(grid1d((long long)rows * C)), dim3(256), s, dout, pool_arg, (long long)(rows / pool_k), pool_k, C,
@@ -1898,6 +1909,12 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
         PN2_LAUNCH_CHECK();
         dz = bufs[which];
         which ^= 1;
+    }
+    if (zero_lead) {
+        const long long total = (long long)rows * dx_first_col;
+        PN2_LAUNCH("zero_lead", 4.0 * total, 0, zero_lead_kernel, dim3(grid1d(total)), dim3(256), s, dx, (long long)lddx,
+                   dx_first_col, total);
+        PN2_LAUNCH_CHECK();
     }
     // BatchNorm-backward partials of the current layer already in ws?  (R, cpb): row-block size and chunks per block
     int fused_R = pooled_R, fused_cpb = pooled_R ? 1 : 0;

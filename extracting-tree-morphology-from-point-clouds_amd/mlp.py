@@ -185,7 +185,7 @@ class _ChainFn(torch.autograd.Function):
         else:
             dx = torch.empty(rows, cin0, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
             if dx is not None and skip:
-                dx[:, :skip].zero_()
+                flags |= _hip.CHAIN_ZERO_LEAD
         sa = torch.empty(rows * maxc, dtype=torch.float32, device=dev)
         sb = torch.empty(rows * maxc, dtype=torch.float32, device=dev)
         seg_ptr, seg_keep = _hip.segments_arg(meta.get("seg_off") if ctx.nseg > 1 else None)

@@ -325,6 +325,10 @@ typedef struct pn2_segments {
  * (`out` may be NULL): the consumer is a linked chain (pn2_mlp_layer.in_stats) that reads `y` and `stats` of that layer.
  * Saves one read and one write of rows x cout floats.  Not with pool_k > 1. */
 #define PN2_CHAIN_LAZY_OUT 0x400
+/* pn2_mlp_chain_bwd_f32 only, OR-ed into `precision`: columns [0, dx_first_col) of dx are ZEROED by the call instead of
+ * left untouched (inside the max-pool scatter launch when there is one -- no launch of its own).  Not with
+ * PN2_CHAIN_ACCUMULATE_DX. */
+#define PN2_CHAIN_ZERO_LEAD 0x800
 
 size_t pn2_mlp_workspace_bytes(int rows, const pn2_mlp_layer *layers, int nlayers, int nseg);
 int pn2_mlp_chain_fwd_f32(const float *x, int64_t ldx, int rows, const pn2_mlp_layer *layers, int nlayers,

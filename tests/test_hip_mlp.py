@@ -109,6 +109,29 @@ def test_pooled_chain_two_pass_sums(chain_rows, monkeypatch):
     test_chain_forward_backward(chain_rows, 16 * 8, 259, [256, 256, 512], 16, True, nn.Conv2d, nn.BatchNorm2d)
 
 
+@pytest.mark.parametrize("pool_k", [32, 1])
+def test_leading_columns_of_dx_come_back_zero(chain_rows, pool_k):
+    """dx_first_col: the input gradient is computed from that column on and the columns in front of it come back as exact
+    zeros (zeroed inside the max-pool scatter launch of a pooled chain, by a launch of its own otherwise)."""
+    rows, cin = 32 * 64, 67
+    layers = build([64, 64, 128], cin, nn.Conv2d, nn.BatchNorm2d, seed=3)
+    for c_, b_, _ in layers:
+        c_.cuda()
+        b_.cuda().train()
+    torch.manual_seed(9)
+    x0 = torch.randn(rows, cin, device="cuda")
+    grads = []
+    for skip in (0, 3):
+        x = x0.clone().requires_grad_(True)
+        out = chain_rows(x, layers, pool_k=pool_k, dx_first_col=skip)
+        torch.manual_seed(10)
+        out.backward(torch.randn_like(out))
+        grads.append(x.grad.clone())
+    assert float(grads[1][:, :3].abs().max()) == 0.0
+    assert torch.equal(grads[1][:, 3:], grads[0][:, 3:]) or rel(grads[1][:, 3:].double().cpu(), grads[0][:, 3:].double().cpu()) < 1e-6
+    assert float(grads[0][:, :3].abs().max()) > 0.0
+
+
 def test_running_stats_and_eval_mode(chain_rows):
     layers = build([16, 8], 5, nn.Conv1d, nn.BatchNorm1d, seed=3)
     ref = [(nn.Conv1d(5, 16, 1), nn.BatchNorm1d(16)), (nn.Conv1d(16, 8, 1), nn.BatchNorm1d(8))]
