@@ -33,11 +33,13 @@ def mask_ranks(pad, masks_off):
 
 
 class MaskedPointLoss(torch.autograd.Function):
-    """(sem [R,2], off [R,3], pad, off_mask, cum_pad, cum_off, sem_labels, off_labels) -> tensor [2] =
-    (semantic loss, offset loss) of the masked rows; one forward and one backward kernel (csrc/loss.hip)."""
+    """(sem [R,2], off [R,3], pad, off_mask, cum_pad, cum_off, sem_labels, off_labels[, weights]) -> tensor [2] =
+    (semantic loss, offset loss) of the masked rows; one forward and one backward kernel (csrc/loss.hip).
+    With weights [2] (get_loss's multipliers): -> (total [], parts [2]) = (w0 sem + w1 off, (w0 sem, w1 off)); only the
+    total carries a gradient, the parts are for the log."""
 
     @staticmethod
-    def forward(ctx, sem, off, pad, off_mask, cum_pad, cum_off, sem_labels, off_labels):
+    def forward(ctx, sem, off, pad, off_mask, cum_pad, cum_off, sem_labels, off_labels, weights=None):
         _hip.require_device(sem, off)
         lib = _hip.lib()
         sem, off = sem.contiguous(), off.contiguous()
@@ -45,6 +47,17 @@ class MaskedPointLoss(torch.autograd.Function):
         R = sem.shape[0]
         out = torch.empty(2, dtype=torch.float32, device=sem.device)
         ws = torch.empty(max(lib.pn2_point_loss_workspace_bytes(R), 16), dtype=torch.uint8, device=sem.device)
+        ctx.weighted = weights is not None
+        if ctx.weighted:
+            weights = weights.contiguous().float()
+            total = torch.empty((), dtype=torch.float32, device=sem.device)
+            _hip.call("point_loss_fwd", lib.pn2_point_loss_weighted_fwd_f32, sem.data_ptr(), off.data_ptr(), pad.data_ptr(),
+                      off_mask.data_ptr(), cum_pad.data_ptr(), cum_off.data_ptr(), sem_labels.data_ptr(), sem_labels.numel(),
+                      off_labels.data_ptr(), off_labels.shape[0], R, weights.data_ptr(), out.data_ptr(), total.data_ptr(),
+                      ws.data_ptr(), ws.numel(), _hip.stream_ptr())
+            ctx.save_for_backward(sem, off, pad, off_mask, cum_pad, cum_off, sem_labels, off_labels, weights)
+            ctx.mark_non_differentiable(out)
+            return total, out
         _hip.call("point_loss_fwd", lib.pn2_point_loss_fwd_f32, sem.data_ptr(), off.data_ptr(), pad.data_ptr(),
                   off_mask.data_ptr(), cum_pad.data_ptr(), cum_off.data_ptr(), sem_labels.data_ptr(), sem_labels.numel(),
                   off_labels.data_ptr(), off_labels.shape[0], R, out.data_ptr(), ws.data_ptr(), ws.numel(), _hip.stream_ptr())
@@ -52,15 +65,21 @@ class MaskedPointLoss(torch.autograd.Function):
         return out
 
     @staticmethod
-    def backward(ctx, g):
-        sem, off, pad, off_mask, cum_pad, cum_off, sem_labels, off_labels = ctx.saved_tensors
+    def backward(ctx, g, *_):
+        sem, off, pad, off_mask, cum_pad, cum_off, sem_labels, off_labels = ctx.saved_tensors[:8]
         g = g.contiguous().float()
         dsem, doff = torch.empty_like(sem), torch.empty_like(off)
-        _hip.call("point_loss_bwd", _hip.lib().pn2_point_loss_bwd_f32, sem.data_ptr(), off.data_ptr(), pad.data_ptr(),
-                  off_mask.data_ptr(), cum_pad.data_ptr(), cum_off.data_ptr(), sem_labels.data_ptr(), sem_labels.numel(),
-                  off_labels.data_ptr(), off_labels.shape[0], sem.shape[0], g.data_ptr(), dsem.data_ptr(), doff.data_ptr(),
-                  _hip.stream_ptr())
-        return dsem, doff, None, None, None, None, None, None
+        if ctx.weighted:
+            _hip.call("point_loss_bwd", _hip.lib().pn2_point_loss_weighted_bwd_f32, sem.data_ptr(), off.data_ptr(), pad.data_ptr(),
+                      off_mask.data_ptr(), cum_pad.data_ptr(), cum_off.data_ptr(), sem_labels.data_ptr(), sem_labels.numel(),
+                      off_labels.data_ptr(), off_labels.shape[0], sem.shape[0], g.data_ptr(), ctx.saved_tensors[8].data_ptr(),
+                      dsem.data_ptr(), doff.data_ptr(), _hip.stream_ptr())
+        else:
+            _hip.call("point_loss_bwd", _hip.lib().pn2_point_loss_bwd_f32, sem.data_ptr(), off.data_ptr(), pad.data_ptr(),
+                      off_mask.data_ptr(), cum_pad.data_ptr(), cum_off.data_ptr(), sem_labels.data_ptr(), sem_labels.numel(),
+                      off_labels.data_ptr(), off_labels.shape[0], sem.shape[0], g.data_ptr(), dsem.data_ptr(), doff.data_ptr(),
+                      _hip.stream_ptr())
+        return dsem, doff, None, None, None, None, None, None, None
 
 
 @cuda_cast

@@ -160,11 +160,11 @@ class PointNet2(nn.Module):
             off_mask = pad & masks_off.index_select(0, (cum_pad - 1).clamp(0, masks_off.numel() - 1))
             cum_off = torch.cumsum(off_mask, 0)
         if fused:
-            both = MaskedPointLoss.apply(sem, off, pad, off_mask, cum_pad, cum_off, semantic_labels.reshape(-1), offset_labels)
-            # both multipliers in one multiply and the total as one reduction: the scalar arithmetic of the generic path below
-            # (two selects, two multiplies, two adds and their backward nodes) is ten launches of a few microseconds each
-            weighted = both * self._loss_weights(both.device)
-            return weighted.sum(), {"semantic_loss": weighted[0], "offset_loss": weighted[1]}
+            # both multipliers and the total inside the loss kernels: the scalar arithmetic of the generic path below (two
+            # selects, two multiplies, two adds and their backward nodes) is ten launches of a few microseconds each
+            total, parts = MaskedPointLoss.apply(sem, off, pad, off_mask, cum_pad, cum_off, semantic_labels.reshape(-1),
+                                                 offset_labels, self._loss_weights(sem.device))
+            return total, {"semantic_loss": parts[0], "offset_loss": parts[1]}
         else:
             rank = (cum_pad - 1).clamp(0, semantic_labels.numel() - 1)
             n_valid, n_off = cum_pad[-1].clamp_min(1), cum_off[-1].clamp_min(1)

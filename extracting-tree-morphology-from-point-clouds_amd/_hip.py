@@ -56,6 +56,10 @@ SIGNATURES = {
     "pn2_point_loss_workspace_bytes": (_sz, [_int]),
     "pn2_point_loss_fwd_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _int, _vp, _vp, _sz, _vp]),
     "pn2_point_loss_bwd_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _int, _vp, _vp, _vp, _vp]),
+    "pn2_point_loss_weighted_fwd_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _int, _vp, _vp, _vp, _vp, _sz,
+                                               _vp]),
+    "pn2_point_loss_weighted_bwd_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _int, _vp, _vp, _vp, _vp,
+                                               _vp]),
     "pn2_knn_radius_f64": (_int, [_vp, _int, _int, ctypes.c_double, _vp, _vp, _vp, _vp]),
     "pn2_cov_eig_f64": (_int, [_vp, _int, _vp, _int, _int, _vp, _vp, _vp]),
     "pn2_knn_grid_workspace_bytes": (_sz, [_int]),
@@ -81,6 +85,7 @@ SIGNATURES = {
     "pn2_gather_grad_f32": (_int, [_vp, _vp, _int, _int, _int, _int, _vp, _vp]),
     "pn2_three_nn_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _int, _int, _int, _vp, _vp, _vp, _vp, _vp]),
     "pn2_three_interpolate_f32": (_int, [_vp, _i64, _i64, _i64, _vp, _vp, _int, _int, _int, _int, _vp, _i64, _i64, _vp, _vp]),
+    "pn2_three_interpolate_concat_f32": (_int, [_vp, _i64, _i64, _i64, _int, _vp, _i64, _i64, _i64, _vp, _vp, _int, _int, _int, _int, _vp, _i64, _i64, _vp, _vp]),
     "pn2_three_interpolate_grad_workspace_bytes": (_sz, [_int, _int, _int, _int]),
     "pn2_three_interpolate_grad_f32": (_int, [_vp, _i64, _i64, _vp, _vp, _int, _int, _int, _int, _vp, _vp, _sz, _vp]),
     "pn2_prof_enable": (None, [_int]),

@@ -77,9 +77,11 @@ __global__ __launch_bounds__(kBlock) void point_loss_fwd_kernel(const float* __r
     }
 }
 
-// out[0] = semantic, out[1] = offset; counts clamped to >= 1 like the host expression
+// out[0] = semantic, out[1] = offset; counts clamped to >= 1 like the host expression.  With weights: out[k] *= weights[k]
+// and *total = out[0] + out[1] (the loss multipliers and the sum of get_loss, PointNet2.py:198-207).
 __global__ void point_loss_finalize_kernel(const double* __restrict__ partial, int nblk, const int64_t* __restrict__ cum_pad,
-                                           const int64_t* __restrict__ cum_off, int R, float* __restrict__ out) {
+                                           const int64_t* __restrict__ cum_off, int R, float* __restrict__ out,
+                                           const float* __restrict__ weights, float* __restrict__ total) {
     double s1 = 0.0, s2 = 0.0;
     for (int i = threadIdx.x; i < nblk; i += 64) s1 += partial[i * 2], s2 += partial[i * 2 + 1];
 #pragma unroll
@@ -89,8 +91,14 @@ __global__ void point_loss_finalize_kernel(const double* __restrict__ partial, i
     }
     if (threadIdx.x == 0) {
         const long long nv = cum_pad[R - 1] > 1 ? cum_pad[R - 1] : 1, no = cum_off[R - 1] > 1 ? cum_off[R - 1] : 1;
-        out[0] = (float)(s1 / (double)nv);
-        out[1] = (float)(s2 / (double)no);
+        float a = (float)(s1 / (double)nv), b = (float)(s2 / (double)no);
+        if (weights) {
+            a = __fmul_rn(a, weights[0]);
+            b = __fmul_rn(b, weights[1]);
+            *total = __fadd_rn(a, b);
+        }
+        out[0] = a;
+        out[1] = b;
     }
 }
 
@@ -101,9 +109,11 @@ __global__ __launch_bounds__(kBlock) void point_loss_bwd_kernel(const float* __r
                                                                 const int64_t* __restrict__ sem_lab, long long n_sem,
                                                                 const float* __restrict__ off_lab, long long n_off_lab, int R,
                                                                 const float* __restrict__ g, float* __restrict__ dsem,
-                                                                float* __restrict__ doff) {
+                                                                float* __restrict__ doff, const float* __restrict__ weights) {
     const long long nv = cum_pad[R - 1] > 1 ? cum_pad[R - 1] : 1, no = cum_off[R - 1] > 1 ? cum_off[R - 1] : 1;
-    const float gs = g[0] / (float)nv, go = g[1] / (float)no;
+    // weights: g is the gradient of the weighted TOTAL (one float)
+    const float g0 = weights ? __fmul_rn(g[0], weights[0]) : g[0], g1 = weights ? __fmul_rn(g[0], weights[1]) : g[1];
+    const float gs = g0 / (float)nv, go = g1 / (float)no;
     for (int r = blockIdx.x * kBlock + threadIdx.x; r < R; r += gridDim.x * kBlock) {
         float ce, dist, p0, p1, dx, dy, dz, sq;
         int label;
@@ -211,10 +221,10 @@ __global__ __launch_bounds__(kRankBlock) void mask_ranks_kernel(const unsigned c
 
 extern "C" size_t pn2_point_loss_workspace_bytes(int R) { return R > 0 ? (size_t)loss_blocks(R) * 2 * sizeof(double) : 0; }
 
-extern "C" int pn2_point_loss_fwd_f32(const float* sem, const float* off, const unsigned char* pad, const unsigned char* off_mask,
-                                      const int64_t* cum_pad, const int64_t* cum_off, const int64_t* sem_labels, int64_t n_sem,
-                                      const float* off_labels, int64_t n_off, int R, float* out2, void* workspace,
-                                      size_t workspace_bytes, void* stream) {
+static int point_loss_fwd(const float* sem, const float* off, const unsigned char* pad, const unsigned char* off_mask,
+                          const int64_t* cum_pad, const int64_t* cum_off, const int64_t* sem_labels, int64_t n_sem,
+                          const float* off_labels, int64_t n_off, int R, float* out2, void* workspace, size_t workspace_bytes,
+                          void* stream, const float* weights, float* total) {
     if (!sem || !off || !pad || !off_mask || !cum_pad || !cum_off || !sem_labels || !off_labels || !out2 || !workspace || R <= 0 ||
         n_sem <= 0 || n_off <= 0)
         return PN2_E_BADARG;
@@ -225,7 +235,39 @@ extern "C" int pn2_point_loss_fwd_f32(const float* sem, const float* off, const 
                (const bool*)off_mask, cum_pad, cum_off, sem_labels, (long long)n_sem, off_labels, (long long)n_off, R,
                (double*)workspace);
     PN2_LAUNCH("point_loss_fwd", 16.0 * nblk, 0, point_loss_finalize_kernel, dim3(1), dim3(64), s, (const double*)workspace, nblk,
-               cum_pad, cum_off, R, out2);
+               cum_pad, cum_off, R, out2, weights, total);
+    PN2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pn2_point_loss_fwd_f32(const float* sem, const float* off, const unsigned char* pad, const unsigned char* off_mask,
+                                      const int64_t* cum_pad, const int64_t* cum_off, const int64_t* sem_labels, int64_t n_sem,
+                                      const float* off_labels, int64_t n_off, int R, float* out2, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+    return point_loss_fwd(sem, off, pad, off_mask, cum_pad, cum_off, sem_labels, n_sem, off_labels, n_off, R, out2, workspace,
+                          workspace_bytes, stream, nullptr, nullptr);
+}
+
+extern "C" int pn2_point_loss_weighted_fwd_f32(const float* sem, const float* off, const unsigned char* pad,
+                                               const unsigned char* off_mask, const int64_t* cum_pad, const int64_t* cum_off,
+                                               const int64_t* sem_labels, int64_t n_sem, const float* off_labels, int64_t n_off,
+                                               int R, const float* weights2, float* out2, float* total, void* workspace,
+                                               size_t workspace_bytes, void* stream) {
+    if (!weights2 || !total) return PN2_E_BADARG;
+    return point_loss_fwd(sem, off, pad, off_mask, cum_pad, cum_off, sem_labels, n_sem, off_labels, n_off, R, out2, workspace,
+                          workspace_bytes, stream, weights2, total);
+}
+
+static int point_loss_bwd(const float* sem, const float* off, const unsigned char* pad, const unsigned char* off_mask,
+                          const int64_t* cum_pad, const int64_t* cum_off, const int64_t* sem_labels, int64_t n_sem,
+                          const float* off_labels, int64_t n_off, int R, const float* grad2, float* dsem, float* doff, void* stream,
+                          const float* weights) {
+    if (!sem || !off || !pad || !off_mask || !cum_pad || !cum_off || !sem_labels || !off_labels || !grad2 || !dsem || !doff ||
+        R <= 0 || n_sem <= 0 || n_off <= 0)
+        return PN2_E_BADARG;
+    PN2_LAUNCH("point_loss_bwd", 58.0 * R, 0, point_loss_bwd_kernel, dim3(loss_blocks(R)), dim3(kBlock), (hipStream_t)stream, sem,
+               off, (const bool*)pad, (const bool*)off_mask, cum_pad, cum_off, sem_labels, (long long)n_sem, off_labels,
+               (long long)n_off, R, grad2, dsem, doff, weights);
     PN2_LAUNCH_CHECK();
     return 0;
 }
@@ -234,14 +276,18 @@ extern "C" int pn2_point_loss_bwd_f32(const float* sem, const float* off, const 
                                       const int64_t* cum_pad, const int64_t* cum_off, const int64_t* sem_labels, int64_t n_sem,
                                       const float* off_labels, int64_t n_off, int R, const float* grad2, float* dsem, float* doff,
                                       void* stream) {
-    if (!sem || !off || !pad || !off_mask || !cum_pad || !cum_off || !sem_labels || !off_labels || !grad2 || !dsem || !doff ||
-        R <= 0 || n_sem <= 0 || n_off <= 0)
-        return PN2_E_BADARG;
-    PN2_LAUNCH("point_loss_bwd", 58.0 * R, 0, point_loss_bwd_kernel, dim3(loss_blocks(R)), dim3(kBlock), (hipStream_t)stream, sem,
-               off, (const bool*)pad, (const bool*)off_mask, cum_pad, cum_off, sem_labels, (long long)n_sem, off_labels,
-               (long long)n_off, R, grad2, dsem, doff);
-    PN2_LAUNCH_CHECK();
-    return 0;
+    return point_loss_bwd(sem, off, pad, off_mask, cum_pad, cum_off, sem_labels, n_sem, off_labels, n_off, R, grad2, dsem, doff,
+                          stream, nullptr);
+}
+
+extern "C" int pn2_point_loss_weighted_bwd_f32(const float* sem, const float* off, const unsigned char* pad,
+                                               const unsigned char* off_mask, const int64_t* cum_pad, const int64_t* cum_off,
+                                               const int64_t* sem_labels, int64_t n_sem, const float* off_labels, int64_t n_off,
+                                               int R, const float* grad_total, const float* weights2, float* dsem, float* doff,
+                                               void* stream) {
+    if (!weights2) return PN2_E_BADARG;
+    return point_loss_bwd(sem, off, pad, off_mask, cum_pad, cum_off, sem_labels, n_sem, off_labels, n_off, R, grad_total, dsem,
+                          doff, stream, weights2);
 }
 
 extern "C" int pn2_mask_ranks(const unsigned char* pad, const unsigned char* masks_off, long long R, long long n_mask,

@@ -149,7 +149,10 @@ __global__ __launch_bounds__(kBlock) void three_interpolate_kernel(const float* 
                                                                    const float* __restrict__ w, int N, int S, int D,
                                                                    float* __restrict__ out, int64_t out_stride,
                                                                    int64_t out_offset, long long total, int32_t* status,
-                                                                   const int* __restrict__ coff) {
+                                                                   const int* __restrict__ coff, const float* __restrict__ skip,
+                                                                   int64_t kb, int64_t kn, int64_t kc, int DK) {
+    // skip (regular batches only): [B,N,DK] rows copied into columns [0, DK) of out -- the concat of blocks.py:208 in the
+    // same launch; the thread that interpolates channel group c of a row also copies the skip groups c, c + DV, ...
     const int DV = D / V;
     // ragged batch: blockIdx.y = cloud, the x-range covers the longest cloud; idx / w / out are packed rows
     long long e_begin = (long long)blockIdx.x * kBlock + threadIdx.x, e_step = (long long)gridDim.x * kBlock, row0 = 0;
@@ -172,6 +175,15 @@ __global__ __launch_bounds__(kBlock) void three_interpolate_kernel(const float* 
         const float w0 = w[r * 3], w1 = w[r * 3 + 1], w2 = w[r * 3 + 2];
         const float* base = points2 + (int64_t)b * pb;
         float* o = out + r * out_stride + out_offset + c;
+        if (skip) {
+            const float* sk = skip + (int64_t)b * kb + (r - (long long)b * N) * kn;
+            for (int q = c; q < DK; q += D) {
+                if (V == 4)
+                    *(float4*)(out + r * out_stride + q) = *(const float4*)(sk + q);
+                else
+                    out[r * out_stride + q] = sk[(int64_t)q * kc];
+            }
+        }
         if (V == 4) {
             const float4 a = *(const float4*)(base + (int64_t)j0 * pn + c);
             const float4 bq = *(const float4*)(base + (int64_t)j1 * pn + c);
@@ -476,26 +488,49 @@ extern "C" int pn2_square_distance_f32(const float* src, int64_t ab, int64_t an,
     return 0;
 }
 
-extern "C" int pn2_three_interpolate_f32(const float* points2, int64_t pb, int64_t pn, int64_t pc, const int32_t* idx,
-                                         const float* w, int B, int N, int S, int D, float* out, int64_t out_stride,
-                                         int64_t out_offset, int32_t* status, void* stream) {
+// skip == nullptr: plain interpolation into columns [out_offset, out_offset + D)
+static int interpolate_run(const float* points2, int64_t pb, int64_t pn, int64_t pc, const int32_t* idx, const float* w, int B,
+                           int N, int S, int D, float* out, int64_t out_stride, int64_t out_offset, int32_t* status, void* stream,
+                           const float* skip, int64_t kb, int64_t kn, int64_t kc, int DK) {
     if (!points2 || !idx || !w || !out || B <= 0 || N <= 0 || S <= 0 || D <= 0 || out_stride < out_offset + D)
         return PN2_E_BADARG;
-    const bool vec = pc == 1 && D % 4 == 0 && pn % 4 == 0 && pb % 4 == 0 && out_stride % 4 == 0 && out_offset % 4 == 0 &&
-                     ((uintptr_t)points2 % 16 == 0) && ((uintptr_t)out % 16 == 0);
+    if (skip && (DK <= 0 || DK > out_offset)) return PN2_E_BADARG;
+    bool vec = pc == 1 && D % 4 == 0 && pn % 4 == 0 && pb % 4 == 0 && out_stride % 4 == 0 && out_offset % 4 == 0 &&
+               ((uintptr_t)points2 % 16 == 0) && ((uintptr_t)out % 16 == 0);
+    if (skip) vec = vec && kc == 1 && DK % 4 == 0 && kn % 4 == 0 && kb % 4 == 0 && ((uintptr_t)skip % 16 == 0);
     hipStream_t s = (hipStream_t)stream;
-    const double ti_bytes = (double)B * N * (36.0 + 4.0 * D) + 4.0 * B * S * D;
+    const double ti_bytes = (double)B * N * (36.0 + 4.0 * D + (skip ? 8.0 * DK : 0.0)) + 4.0 * B * S * D;
     if (vec) {
         const long long total = (long long)B * N * (D / 4);
         PN2_LAUNCH("three_interpolate", ti_bytes, 0, (three_interpolate_kernel<4>), dim3(grid_for(total)), dim3(kBlock), s,
-                   points2, pb, pn, pc, idx, w, N, S, D, out, out_stride, out_offset, total, status, (const int*)nullptr);
+                   points2, pb, pn, pc, idx, w, N, S, D, out, out_stride, out_offset, total, status, (const int*)nullptr, skip, kb,
+                   kn, kc, DK);
     } else {
         const long long total = (long long)B * N * D;
         PN2_LAUNCH("three_interpolate", ti_bytes, 0, (three_interpolate_kernel<1>), dim3(grid_for(total)), dim3(kBlock), s,
-                   points2, pb, pn, pc, idx, w, N, S, D, out, out_stride, out_offset, total, status, (const int*)nullptr);
+                   points2, pb, pn, pc, idx, w, N, S, D, out, out_stride, out_offset, total, status, (const int*)nullptr, skip, kb,
+                   kn, kc, DK);
     }
     PN2_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int pn2_three_interpolate_f32(const float* points2, int64_t pb, int64_t pn, int64_t pc, const int32_t* idx,
+                                         const float* w, int B, int N, int S, int D, float* out, int64_t out_stride,
+                                         int64_t out_offset, int32_t* status, void* stream) {
+    return interpolate_run(points2, pb, pn, pc, idx, w, B, N, S, D, out, out_stride, out_offset, status, stream, nullptr, 0, 0, 0,
+                           0);
+}
+
+// ... and the skip connection's rows points1 [B,N,D1] (strided) into columns [0, D1) of out in the same launch: the whole
+// cat([points1, interpolated], -1) of blocks.py:208.  out_offset >= D1.
+extern "C" int pn2_three_interpolate_concat_f32(const float* points1, int64_t kb, int64_t kn, int64_t kc, int D1,
+                                                const float* points2, int64_t pb, int64_t pn, int64_t pc, const int32_t* idx,
+                                                const float* w, int B, int N, int S, int D, float* out, int64_t out_stride,
+                                                int64_t out_offset, int32_t* status, void* stream) {
+    if (!points1) return PN2_E_BADARG;
+    return interpolate_run(points2, pb, pn, pc, idx, w, B, N, S, D, out, out_stride, out_offset, status, stream, points1, kb, kn,
+                           kc, D1);
 }
 
 // bucketing pays off once the op is large; below this many atomics the direct kernel is faster
@@ -595,11 +630,11 @@ extern "C" int pn2_three_interpolate_ragged_f32(const float* points2, const int3
     if (vec) {
         const long long per = (long long)n_max * (D / 4);
         PN2_LAUNCH("three_interpolate", ti_bytes, 0, (three_interpolate_kernel<4>), dim3(grid_for(per), C), dim3(kBlock), s, points2,
-                   pb, pn, (int64_t)1, idx, w, n_max, S, D, out, out_stride, out_offset, per, status, (const int*)coff);
+                   pb, pn, (int64_t)1, idx, w, n_max, S, D, out, out_stride, out_offset, per, status, (const int*)coff, (const float*)nullptr, (int64_t)0, (int64_t)0, (int64_t)0, 0);
     } else {
         const long long per = (long long)n_max * D;
         PN2_LAUNCH("three_interpolate", ti_bytes, 0, (three_interpolate_kernel<1>), dim3(grid_for(per), C), dim3(kBlock), s, points2,
-                   pb, pn, (int64_t)1, idx, w, n_max, S, D, out, out_stride, out_offset, per, status, (const int*)coff);
+                   pb, pn, (int64_t)1, idx, w, n_max, S, D, out, out_stride, out_offset, per, status, (const int*)coff, (const float*)nullptr, (int64_t)0, (int64_t)0, (int64_t)0, 0);
     }
     PN2_LAUNCH_CHECK();
     return 0;

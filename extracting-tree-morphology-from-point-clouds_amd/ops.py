@@ -287,11 +287,16 @@ class ThreeInterpolateConcat(torch.autograd.Function):
         _check_idx(idx32, S, "three_interpolate")
         w = w.contiguous()
         out = torch.empty(B, N, D1 + D2, dtype=torch.float32, device=points2.device)
-        if D1:
-            out[:, :, :D1].copy_(points1)
-        _hip.call("three_interpolate", _hip.lib().pn2_three_interpolate_f32, points2.data_ptr(), *_strides3(points2),
-                  idx32.data_ptr(), w.data_ptr(), B, N, S, D2, out.data_ptr(), D1 + D2, D1,
-                  status_word(points2.device).data_ptr(), _hip.stream_ptr(), nbytes=B * N * (3 * 12 + 4 * D2) + 4 * B * S * D2)
+        if D1:   # the skip rows are copied by the same launch
+            points1 = _hip.f32(points1)
+            _hip.call("three_interpolate", _hip.lib().pn2_three_interpolate_concat_f32, points1.data_ptr(), *_strides3(points1), D1,
+                      points2.data_ptr(), *_strides3(points2), idx32.data_ptr(), w.data_ptr(), B, N, S, D2, out.data_ptr(), D1 + D2,
+                      D1, status_word(points2.device).data_ptr(), _hip.stream_ptr(),
+                      nbytes=B * N * (3 * 12 + 4 * D2 + 8 * D1) + 4 * B * S * D2)
+        else:
+            _hip.call("three_interpolate", _hip.lib().pn2_three_interpolate_f32, points2.data_ptr(), *_strides3(points2),
+                      idx32.data_ptr(), w.data_ptr(), B, N, S, D2, out.data_ptr(), D1 + D2, D1,
+                      status_word(points2.device).data_ptr(), _hip.stream_ptr(), nbytes=B * N * (3 * 12 + 4 * D2) + 4 * B * S * D2)
         ctx.save_for_backward(idx32, w)
         ctx.dims = (B, N, S, D1, D2)
         return out

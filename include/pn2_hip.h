@@ -164,6 +164,17 @@ int pn2_point_loss_bwd_f32(const float *sem, const float *off, const unsigned ch
                            const float *off_labels, int64_t n_off, int R, const float *grad2, float *dsem, float *doff,
                            void *stream);
 
+/* The same with get_loss's two multipliers and its sum folded in (PointNet2.py:198-207): out2 = (w0 * semantic, w1 * offset),
+ * *total = their sum; the backward takes the gradient of the TOTAL (one float on the device). */
+int pn2_point_loss_weighted_fwd_f32(const float *sem, const float *off, const unsigned char *pad, const unsigned char *off_mask,
+                                    const int64_t *cum_pad, const int64_t *cum_off, const int64_t *sem_labels, int64_t n_sem,
+                                    const float *off_labels, int64_t n_off, int R, const float *weights2, float *out2,
+                                    float *total, void *workspace, size_t workspace_bytes, void *stream);
+int pn2_point_loss_weighted_bwd_f32(const float *sem, const float *off, const unsigned char *pad, const unsigned char *off_mask,
+                                    const int64_t *cum_pad, const int64_t *cum_off, const int64_t *sem_labels, int64_t n_sem,
+                                    const float *off_labels, int64_t n_off, int R, const float *grad_total,
+                                    const float *weights2, float *dsem, float *doff, void *stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * kNN feature helpers               replaces the neighbourhood work of Modules/Features.py:111-175
  *   (compute_normals_ckdtree :111-133, compute_curvature_ckdtree :136-158, compute_density_ckdtree :161-173,
@@ -196,6 +207,12 @@ int pn2_knn_radius_grid_f64(const double *points, int N, int k, double r2, int32
 int pn2_three_interpolate_f32(const float *points2, int64_t pb, int64_t pn, int64_t pc, const int32_t *idx,
                               const float *w, int B, int N, int S, int D, float *out, int64_t out_stride,
                               int64_t out_offset, int32_t *status, void *stream);
+/* The same with the skip connection's rows points1 [B,N,D1] (strided) copied into columns [0, D1) of out by the same launch:
+ * cat([points1, interpolated], -1) of blocks.py:208 in one pass.  out_offset >= D1. */
+int pn2_three_interpolate_concat_f32(const float *points1, int64_t kb, int64_t kn, int64_t kc, int D1,
+                                     const float *points2, int64_t pb, int64_t pn, int64_t pc, const int32_t *idx,
+                                     const float *w, int B, int N, int S, int D, float *out, int64_t out_stride,
+                                     int64_t out_offset, int32_t *status, void *stream);
 /* dpoints2 [B,S,D] (dense, zeroed by the call) += w * dout[:, out_offset : out_offset+D]
  * workspace: pn2_three_interpolate_grad_workspace_bytes(B,N,S,D) bytes (large calls bucket the contributions by
  * destination before summing them). */
