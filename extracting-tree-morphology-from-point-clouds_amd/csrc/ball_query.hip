@@ -117,43 +117,62 @@ __global__ __launch_bounds__(kBlock) void ball_query_kernel(const float* __restr
         qz2[i / 2] = pn2::f2{qz[i], qz[i + 1]};
         qn2[i / 2] = pn2::f2{qn[i], qn[i + 1]};
     }
-    // the loads of block n0 + 64 are in flight while block n0 is tested
-    float nx, ny, nz;
-    c.load(n_begin + lane < n_end ? n_begin + lane : n_begin, nx, ny, nz);
-    for (int n0 = n_begin; n0 < n_end; n0 += 64) {
-        const int n = n0 + lane;
-        const bool ok = n < n_end;
-        const float x = nx, y = ny, z = nz;
-        c.load(n + 64 < n_end ? n + 64 : n_begin, nx, ny, nz);
-        const float pn = pn2::norm2(x, y, z);
-        const pn2::f2 x2 = {-2.0f * x, -2.0f * x}, y2 = {-2.0f * y, -2.0f * y}, z2 = {-2.0f * z, -2.0f * z},
-                      pn2v = {pn, pn};
-        bool in[Q];
-        bool any = false;
+    // the loads of the next PF blocks of 64 points are in flight while PF blocks are tested (deep levels: a few wavefronts
+    // walk a small cloud end to end, one exposed load latency per step would be all of their time)
+    constexpr int PF = 4;
+    float fx[PF], fy[PF], fz[PF];
 #pragma unroll
-        for (int i = 0; i < Q; i += 2) {
-            const pn2::f2 d = pn2::sqdist2(qx2[i / 2], qy2[i / 2], qz2[i / 2], qn2[i / 2], x2, y2, z2, pn2v);
-            in[i] = ok && !(d.x > r2);
-            in[i + 1] = ok && !(d.y > r2);
-            any |= in[i] | in[i + 1];
+    for (int u = 0; u < PF; ++u) {
+        const int n = n_begin + 64 * u + lane;
+        c.load(n < n_end ? n : n_begin, fx[u], fy[u], fz[u]);
+    }
+    bool done = false;
+    for (int s0 = n_begin; s0 < n_end && !done; s0 += 64 * PF) {
+        float cx[PF], cy[PF], cz[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) cx[u] = fx[u], cy[u] = fy[u], cz[u] = fz[u];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) {
+            const int n = s0 + 64 * (PF + u) + lane;
+            c.load(n < n_end ? n : n_begin, fx[u], fy[u], fz[u]);
         }
-        if (__ballot(any) == 0) continue;  // common case: no lane holds a hit for any of the Q queries
-        bool all_full = true;
 #pragma unroll
-        for (int i = 0; i < Q; ++i) {
-            if (cnt[i] < Keff) {
-                const bool hit = in[i];
-                const u64 m = __ballot(hit);
-                if (m) {
-                    if (cnt[i] == 0) first[i] = n0 + __builtin_ctzll(m);
-                    const int pos = cnt[i] + __popcll(m & lt);
-                    if (hit && pos < Keff) row[i][pos] = n;
-                    cnt[i] += __popcll(m);
-                }
-                all_full = all_full && (cnt[i] >= Keff);
+        for (int u = 0; u < PF; ++u) {
+            const int n0 = s0 + 64 * u;
+            if (n0 >= n_end || done) break;   // uniform
+            const int n = n0 + lane;
+            const bool ok = n < n_end;
+            const float x = cx[u], y = cy[u], z = cz[u];
+            const float pn = pn2::norm2(x, y, z);
+            const pn2::f2 x2 = {-2.0f * x, -2.0f * x}, y2 = {-2.0f * y, -2.0f * y}, z2 = {-2.0f * z, -2.0f * z},
+                          pn2v = {pn, pn};
+            bool in[Q];
+            bool any = false;
+#pragma unroll
+            for (int i = 0; i < Q; i += 2) {
+                const pn2::f2 d = pn2::sqdist2(qx2[i / 2], qy2[i / 2], qz2[i / 2], qn2[i / 2], x2, y2, z2, pn2v);
+                in[i] = ok && !(d.x > r2);
+                in[i + 1] = ok && !(d.y > r2);
+                any |= in[i] | in[i + 1];
             }
+            if (__ballot(any) == 0) continue;  // common case: no lane holds a hit for any of the Q queries
+            bool all_full = true;
+#pragma unroll
+            for (int i = 0; i < Q; ++i) {
+                if (cnt[i] < Keff) {
+                    const bool hit = in[i];
+                    const u64 m = __ballot(hit);
+                    if (m) {
+                        if (cnt[i] == 0) first[i] = n0 + __builtin_ctzll(m);
+                        const int pos = cnt[i] + __popcll(m & lt);
+                        if (hit && pos < Keff) row[i][pos] = n;
+                        cnt[i] += __popcll(m);
+                    }
+                    all_full = all_full && (cnt[i] >= Keff);
+                }
+            }
+            done = all_full;
         }
-        if (all_full) break;
     }
 
 #pragma unroll

@@ -944,12 +944,18 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const float* __res
         const float* p = y + gi * K * C + c;
         float best = -__builtin_inff();
         int bk = 0;
-        for (int k = 0; k < K; ++k) {
-            float v = __builtin_fmaf(p[(long long)k * C] - mean, sc, bt);
-            if (relu) v = fmaxf(v, 0.f);
-            if (v > best) {
-                best = v;
-                bk = k;
+        for (int k0 = 0; k0 < K; k0 += 8) {   // eight independent loads in flight, then the (ordered) comparisons
+            float raw[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) raw[u] = p[(long long)(k0 + u < K ? k0 + u : K - 1) * C];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                float v = __builtin_fmaf(raw[u] - mean, sc, bt);
+                if (relu) v = fmaxf(v, 0.f);
+                if (k0 + u < K && v > best) {
+                    best = v;
+                    bk = k0 + u;
+                }
             }
         }
         out[e] = best;
