@@ -1066,16 +1066,25 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                 bt[j] = coef[ST_BETA * C + cc];
                 is[j] = coef[ST_INVSTD * C + cc];
             }
-            for (int r = r0 + tr; r < r1; r += rg) {
-                const float4 yv = ld4<VEC>(y, ldy, r, c, rows, C);
-                const float4 dv = ld4<VEC>(dz, lddz, r, c, rows, C);
-                const float yy[4] = {yv.x, yv.y, yv.z, yv.w}, dd[4] = {dv.x, dv.y, dv.z, dv.w};
+            for (int rr = r0 + tr; rr < r1; rr += 4 * rg) {   // four rows' loads in flight, summed in row order
+                float4 yv[4], dv[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float t = __builtin_fmaf(yy[j] - mean[j], sc[j], bt[j]);
-                    const float g = (!relu || t > 0.f) ? dd[j] : 0.f;
-                    s1[j] += g;
-                    s2[j] += g * ((yy[j] - mean[j]) * is[j]);
+                for (int u = 0; u < 4; ++u) {
+                    const int r = rr + u * rg < r1 ? rr + u * rg : r1 - 1;
+                    yv[u] = ld4<VEC>(y, ldy, r, c, rows, C);
+                    dv[u] = ld4<VEC>(dz, lddz, r, c, rows, C);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (rr + u * rg >= r1) break;
+                    const float yy[4] = {yv[u].x, yv[u].y, yv[u].z, yv[u].w}, dd[4] = {dv[u].x, dv[u].y, dv[u].z, dv[u].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float t = __builtin_fmaf(yy[j] - mean[j], sc[j], bt[j]);
+                        const float g = (!relu || t > 0.f) ? dd[j] : 0.f;
+                        s1[j] += g;
+                        s2[j] += g * ((yy[j] - mean[j]) * is[j]);
+                    }
                 }
             }
         }

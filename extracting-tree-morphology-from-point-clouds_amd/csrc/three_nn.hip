@@ -127,6 +127,76 @@ __global__ __launch_bounds__(kBlock) void three_nn_kernel(const float* __restric
     }
 }
 
+// (distance, index) order: what an ascending scan with strict comparisons keeps
+__device__ __forceinline__ bool lex_lt(float d, int i, float e, int j) { return d < e || (d == e && i < j); }
+
+// Small clouds (the deep levels: a few hundred dense points): TPP threads share one dense point, thread j of the point scans
+// the samples j, j + TPP, ... and the TPP top-3 lists are merged in (distance, index) order through lane exchanges -- the
+// same three neighbours as one ascending scan, TPP times the wavefronts.  S <= kTile, regular batches.
+template <int TPP>
+__global__ __launch_bounds__(kBlock) void three_nn_small_kernel(const float* __restrict__ xyz1, int64_t ab, int64_t an, int64_t ac,
+                                                                const float* __restrict__ xyz2, int64_t bb, int64_t bn, int64_t bc,
+                                                                int N, int S, int32_t* __restrict__ out_idx,
+                                                                float* __restrict__ out_w, float* __restrict__ out_dist) {
+    __shared__ float4 tile[kTile + TPP];
+    const int b = blockIdx.y;
+    for (int t = threadIdx.x; t < S + TPP; t += kBlock) {
+        const float* q = xyz2 + (int64_t)b * bb + (int64_t)(t < S ? t : S - 1) * bn;
+        const float x = q[0], y = q[bc], z = q[2 * bc];
+        tile[t] = make_float4(-2.0f * x, -2.0f * y, -2.0f * z, pn2::norm2(x, y, z));
+    }
+    __syncthreads();
+    const int gt = blockIdx.x * kBlock + threadIdx.x, n = gt / TPP, sub = gt % TPP;
+    const bool live = n < N;
+    const float* p = xyz1 + (int64_t)b * ab + (int64_t)(live ? n : 0) * an;
+    const float px = p[0], py = p[ac], pz = p[2 * ac];
+    const float pn = pn2::norm2(px, py, pz);
+    float d0 = __builtin_inff(), d1 = d0, d2 = d0;
+    int i0 = 0, i1 = 0, i2 = 0;   // like three_nn_kernel: an infinite distance never enters a list
+    auto insert = [&](float D, int s) {
+        const float D0 = d0, D1 = d1, D2 = d2;
+        const int I0 = i0, I1 = i1, I2 = i2;
+        const bool c2 = lex_lt(D, s, D2, I2), c1 = lex_lt(D, s, D1, I1), c0 = lex_lt(D, s, D0, I0);
+        const float n2 = c2 ? D : D2;
+        const int m2 = c2 ? s : I2;
+        const float n1 = c1 ? D : D1;
+        const int m1 = c1 ? s : I1;
+        d2 = c1 ? D1 : n2;
+        i2 = c1 ? I1 : m2;
+        d1 = c0 ? D0 : n1;
+        i1 = c0 ? I0 : m1;
+        d0 = c0 ? D : D0;
+        i0 = c0 ? s : I0;
+    };
+    float4 q_next = tile[sub];
+    for (int t = sub; t < S; t += TPP) {
+        const float4 q = q_next;
+        q_next = tile[t + TPP];
+        const float m = __builtin_fmaf(pz, q.z, __builtin_fmaf(py, q.y, __fmul_rn(px, q.x)));
+        const float D = __fadd_rn(__fadd_rn(m, pn), q.w);
+        if (__ballot(D < d2)) insert(D, t);   // ascending t per thread: a tie never displaces an earlier sample
+    }
+#pragma unroll
+    for (int o = 1; o < TPP; o <<= 1) {   // the TPP lanes of a point are adjacent: butterfly merge, all end with the full list
+        const float e0 = __shfl_xor(d0, o), e1 = __shfl_xor(d1, o), e2 = __shfl_xor(d2, o);
+        const int j0 = __shfl_xor(i0, o), j1 = __shfl_xor(i1, o), j2 = __shfl_xor(i2, o);
+        insert(e0, j0);
+        insert(e1, j1);
+        insert(e2, j2);
+    }
+    if (!live || sub != 0) return;
+    const size_t o = ((size_t)b * N + n) * 3;
+    out_idx[o] = i0, out_idx[o + 1] = i1, out_idx[o + 2] = i2;
+    if (out_dist) out_dist[o] = d0, out_dist[o + 1] = d1, out_dist[o + 2] = d2;
+    const float r0 = __fdiv_rn(1.0f, d0 < 1e-6f ? 1e-6f : d0);
+    const float r1 = __fdiv_rn(1.0f, d1 < 1e-6f ? 1e-6f : d1);
+    const float r2 = __fdiv_rn(1.0f, d2 < 1e-6f ? 1e-6f : d2);
+    const float sum = __fadd_rn(__fadd_rn(r0, r1), r2);
+    out_w[o] = __fdiv_rn(r0, sum);
+    out_w[o + 1] = __fdiv_rn(r1, sum);
+    out_w[o + 2] = __fdiv_rn(r2, sum);
+}
+
 template <int V>
 struct Vec;
 template <>
@@ -465,6 +535,15 @@ extern "C" int pn2_three_nn_f32(const float* xyz1, int64_t ab, int64_t an, int64
     int P = 1;
     if (const char* e = getenv("PN2_TNN_P")) P = atoi(e);
     const double tnn_bytes = (double)B * (12.0 * N + 12.0 * S + 36.0 * N);
+    // small clouds: several threads per dense point (a launch of a handful of wavefronts is all scan latency otherwise)
+    if (!order && S <= kTile && (long long)B * N <= 16384 && S >= 32 && !getenv("PN2_TNN_NO_SMALL")) {
+        constexpr int TPP = 8;
+        PN2_LAUNCH("three_nn", tnn_bytes, 8.0 * B * (double)N * S, (three_nn_small_kernel<TPP>),
+                   dim3(pn2::ceil_div((long long)N * TPP, kBlock), B), dim3(kBlock), (hipStream_t)stream, xyz1, ab, an, ac, xyz2, bb,
+                   bn, bc, N, S, out_idx, out_w, out_dist);
+        PN2_LAUNCH_CHECK();
+        return 0;
+    }
 #define PN2_TNN_CASE(P_)                                                                                              \
     if (P == P_)                                                                                                      \
         PN2_LAUNCH("three_nn", tnn_bytes, 8.0 * B * (double)N * S, (three_nn_kernel<P_>), dim3(pn2::ceil_div(N, kBlock * P_), B), dim3(kBlock), \

@@ -792,3 +792,28 @@ def test_mask_ranks_equal_the_torch_expressions(pn2):
     assert torch.equal(a, torch.cumsum(base, 0))
     with pytest.raises(RuntimeError):
         mask_ranks(base, mo[:0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N,S", [(1, 1024, 256), (1, 256, 64), (8, 2000, 33), (3, 77, 2048), (2, 8192, 1000), (16, 1000, 32)])
+def test_three_nn_small_clouds_threads_per_point(pn2, monkeypatch, B, N, S):
+    """Small clouds split every dense point's scan over several threads and merge the lists in (distance, index) order:
+    neighbours, distances and weights must be what the one-thread scan (PN2_TNN_NO_SMALL=1) and the oracle give -- with
+    ties: duplicated samples, samples drawn from the cloud, a block of identical points."""
+    from pn2_amd import ops
+    O.build()
+    rng = np.random.default_rng(B * 1000 + N + S)
+    xyz = _cloud(B, N, seed=N + S, scale=0.8, shift=(2.0, -1.0, 5.0))
+    xyz[:, N // 2:N // 2 + 9] = xyz[:, :1]                          # identical dense points
+    pick = rng.integers(0, N, size=S)
+    new_xyz = xyz[:, pick].copy()
+    new_xyz[:, S // 3:S // 3 + 5] = new_xyz[:, :1]                  # identical samples: equal distances, lowest index first
+    dist, want = O.three_nn(xyz, new_xyz)
+    x, q = torch.as_tensor(xyz, device="cuda"), torch.as_tensor(new_xyz, device="cuda")
+    gi, gw, gd = ops.three_nn(x, q, want_dist=True)
+    monkeypatch.setenv("PN2_TNN_NO_SMALL", "1")
+    hi, hw, hd = ops.three_nn(x, q, want_dist=True)
+    assert torch.equal(gi, hi) and torch.equal(gd.view(torch.int32), hd.view(torch.int32))
+    assert torch.equal(gw.view(torch.int32), hw.view(torch.int32))
+    assert np.array_equal(gi.cpu().numpy(), want)
+    assert np.array_equal(gd.cpu().numpy().view(np.uint32), dist.view(np.uint32))
