@@ -2033,7 +2033,11 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
                 st = in.coef ? launch_gemm<false, TR_PLAIN, false, TR_BNRELU, EPI_SLAB>(g, S, wp.tile, s, &nsplit)
                              : launch_gemm<false, TR_PLAIN, false, TR_PLAIN, EPI_SLAB>(g, S, wp.tile, s, &nsplit);
             if (st) return st;
-            if (tasks.n == SLAB_TASKS && !defer_wgrad) flush_slab_tasks(tasks, s);
+            if (!defer_wgrad) {   // never two reductions into the same gradient in one launch (shared weights)
+                bool clash = tasks.n == SLAB_TASKS;
+                for (int t = 0; t < tasks.n && !clash; ++t) clash = tasks.t[t].out == L.dweight;
+                if (clash) flush_slab_tasks(tasks, s);
+            }
             if (tasks.n == SLAB_TASKS) return PN2_E_BADARG;   // more layers than a task table holds
             add_slab_task(tasks, (const float*)arena, nsplit, (long long)L.cout * L.cin, L.dweight);
             arena += align256((size_t)wp.nsplit * L.cout * L.cin * sizeof(float));
@@ -2113,7 +2117,11 @@ extern "C" int pn2_mlp_flush_wgrad(void* stream) {
     hipStream_t s = (hipStream_t)stream;
     SlabTasks T{};
     for (const SlabTask& t : todo) {
-        if (T.n == SLAB_TASKS) flush_slab_tasks(T, s);
+        // two reductions into the SAME gradient (a layer that ran more than once in this backward pass: the mini-batches of
+        // forward_hierarchical) must not share a launch -- their blocks would read-modify-write the same elements
+        bool clash = T.n == SLAB_TASKS;
+        for (int i = 0; i < T.n && !clash; ++i) clash = T.t[i].out == t.out;
+        if (clash) flush_slab_tasks(T, s);
         add_slab_task(T, t.slab, t.nsplit, t.mn, t.out);
     }
     flush_slab_tasks(T, s);

@@ -817,3 +817,32 @@ def test_three_nn_small_clouds_threads_per_point(pn2, monkeypatch, B, N, S):
     assert torch.equal(gw.view(torch.int32), hw.view(torch.int32))
     assert np.array_equal(gi.cpu().numpy(), want)
     assert np.array_equal(gd.cpu().numpy().view(np.uint32), dist.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_layer_used_several_times_in_one_backward_pass(pn2):
+    """forward_hierarchical runs the same layers once per mini-batch and calls backward() once: the deferred weight-gradient
+    reductions of one layer then meet in the flush and must not share a launch (their blocks would read-modify-write the
+    same gradient elements -- lost updates).  Many repeats of one 128 x 128 layer against per-call reductions (which the
+    stream orders) -- bit for bit, several times."""
+    import torch.nn as nn
+    from pn2_amd import mlp, _hip
+    torch.manual_seed(0)
+    layers = [(nn.Conv1d(128, 128, 1).cuda(), nn.BatchNorm1d(128).cuda().train(), True),
+              (nn.Conv1d(128, 128, 1).cuda(), nn.BatchNorm1d(128).cuda().train(), True)]
+    xs = [torch.randn(3000 + 500 * i, 128, device="cuda") for i in range(12)]
+    got = {}
+    for mode, e in (("deferred", {}), ("per_call", {"PN2_NO_DEFER_WGRAD": 1})):
+        for rep in range(3):
+            for conv, bn, _ in layers:
+                conv.weight.grad = bn.weight.grad = bn.bias.grad = None
+            with env(**e):
+                total = sum((mlp.chain_rows(x, layers) ** 2).sum() for x in xs)
+                total.backward()
+                assert _hip.lib().pn2_mlp_drop_wgrad() == 0
+            grads = [layers[0][0].weight.grad.clone(), layers[1][0].weight.grad.clone()]
+            if mode in got:
+                assert all(torch.equal(a, b) for a, b in zip(grads, got[mode])), f"{mode}: run-to-run difference"
+            got[mode] = grads
+    for a, b in zip(got["deferred"], got["per_call"]):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
