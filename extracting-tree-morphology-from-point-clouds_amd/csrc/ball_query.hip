@@ -256,6 +256,10 @@ Plan plan(int B, int N, int S) {
     if (nseg > kMaxSeg) nseg = kMaxSeg;
     if (nseg > nblk / 8) nseg = nblk / 8;  // at least 512 points per segment
     if (nseg < 1) nseg = 1;
+    if (N <= 2048) {   // the deep levels: a scan is 32 steps at most -- more wavefronts (2 queries each), no merge launch
+        Q = 2;         // (1 x 1024 points, 256 queries: (8,2) + merge 19 us, (2,1) 11 us)
+        nseg = 1;
+    }
     if (const char* e = getenv("PN2_BQ_PLAN")) {  // "Q,nseg" -- tuning aid
         int q = 0, g = 0;
         if (sscanf(e, "%d,%d", &q, &g) == 2 && (q == 2 || q == 4 || q == 8) && g >= 1 && g <= kMaxSeg) {
