@@ -1276,26 +1276,35 @@ __global__ __launch_bounds__(NR_T) void narrow_fwd_kernel(const float* __restric
     const int r1 = r0 + NR_ROWS < rb.row_end ? r0 + NR_ROWS : rb.row_end;
     constexpr int RGF = (NR_T / 64) * RPW;
     const int iters = (r1 - r0 + RGF - 1) / RGF;   // uniform trip count: the DPP sums need every lane
-    for (int it = 0; it < iters; ++it) {
-        const int rb = r0 + it * RGF + wave * RPW + rsub;
-        const int r = rb < r1 ? rb : r1 - 1;
-        const float4 v = *(const float4*)(y + (long long)r * ldy + k);
-        const float e[4] = {v.x, v.y, v.z, v.w};
-        float p[NMAX] = {0.f, 0.f, 0.f, 0.f};
+    constexpr int UF = 4;   // rows in flight per lane: the loop is one 16-byte load and a DPP sum per row otherwise
+    for (int it0 = 0; it0 < iters; it0 += UF) {
+        float4 v[UF];
+        int rbu[UF];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float x = e[j];
-            if (HAS_BN) {
-                x = __builtin_fmaf(x - cm[j], cs[j], cb[j]);
-                if (relu) x = fmaxf(x, 0.0f);
-            }
-#pragma unroll
-            for (int n = 0; n < NMAX; ++n) p[n] = __builtin_fmaf(x, w[n][j], p[n]);
+        for (int u = 0; u < UF; ++u) {
+            rbu[u] = r0 + (it0 + u) * RGF + wave * RPW + rsub;
+            const int r = rbu[u] < r1 ? rbu[u] : r1 - 1;
+            v[u] = *(const float4*)(y + (long long)r * ldy + k);
         }
 #pragma unroll
-        for (int n = 0; n < NMAX; ++n) p[n] = group_sum<KL>(p[n]);
-        if (kq == KL - 1 && rb < r1) {
-            for (int n = 0; n < N; ++n) out[(long long)r * N + n] = p[n] + (bias ? bias[n] : 0.0f);
+        for (int u = 0; u < UF; ++u) {   // steps beyond iters compute on the last row and store nothing
+            const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+            float p[NMAX] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float x = e[j];
+                if (HAS_BN) {
+                    x = __builtin_fmaf(x - cm[j], cs[j], cb[j]);
+                    if (relu) x = fmaxf(x, 0.0f);
+                }
+#pragma unroll
+                for (int n = 0; n < NMAX; ++n) p[n] = __builtin_fmaf(x, w[n][j], p[n]);
+            }
+#pragma unroll
+            for (int n = 0; n < NMAX; ++n) p[n] = group_sum<KL>(p[n]);
+            if (kq == KL - 1 && rbu[u] < r1) {
+                for (int n = 0; n < N; ++n) out[(long long)rbu[u] * N + n] = p[n] + (bias ? bias[n] : 0.0f);
+            }
         }
     }
 }
