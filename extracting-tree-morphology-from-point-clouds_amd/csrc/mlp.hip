@@ -995,7 +995,7 @@ __global__ __launch_bounds__(256) void maxpool_scatter_sums_kernel(const float* 
     for (int e = threadIdx.x; e < (r1 - r0) * nlead; e += 256) lead[(long long)(r0 + e / nlead) * ldlead + e % nlead] = 0.0f;
     coef += (long long)rb.seg * ST_ROWS * C;
     const int g0 = r0 / K, g1 = r1 / K;   // segments and row blocks hold whole groups
-    const int cw = C >= 256 ? 256 : (C > 128 ? 256 : C > 64 ? 128 : 64);
+    const int cw = C > 128 ? 256 : C > 64 ? 128 : 64;   // channels worked on in parallel
     const int ng = 256 / cw;              // groups worked on in parallel
     const int tc = threadIdx.x % cw, tg = threadIdx.x / cw;
     for (int c0 = 0; c0 < C; c0 += cw) {
