@@ -846,3 +846,39 @@ def test_layer_used_several_times_in_one_backward_pass(pn2):
             got[mode] = grads
     for a, b in zip(got["deferred"], got["per_call"]):
         assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N,S,K,D,xyz_last", [(2, 1024, 256, 32, 64, False), (3, 100, 50, 32, 64, True), (1, 64, 16, 32, 256, False),
+                                                (2, 500, 40, 16, 6, False), (1, 300, 64, 8, 300, False), (2, 90, 7, 64, 130, False)])
+def test_group_grad_presummed_per_group(pn2, monkeypatch, B, N, S, K, D, xyz_last):
+    """The grouping backward sums the rows of a group that share row 0's destination (the padding of a sparse ball) before
+    they leave as one atomic per channel: equal to the float64 scatter-add and to the row-wise atomic kernel
+    (PN2_GROUP_GRAD_ROWS=1) within rounding -- padded balls, fully distinct balls, arbitrary duplicates."""
+    from pn2_amd import ops
+    rng = np.random.default_rng(N + D)
+    dev = lambda a: torch.as_tensor(a, device="cuda")
+    idx = rng.integers(0, N, size=(B, S, K)).astype(np.int32)
+    cnt = rng.integers(1, K + 1, size=(B, S))
+    pad = np.arange(K)[None, None, :] >= cnt[:, :, None]
+    idx = np.where(pad, idx[:, :, :1], idx)                       # short balls repeat their first hit
+    idx[:, 0, :] = idx[:, 0, ::-1]                                # one group with duplicates elsewhere
+    xyz, new_xyz = dev(_cloud(B, N, 1)), dev(_cloud(B, S, 2))
+    go = rng.normal(size=(B, S, K, 3 + D)).astype(np.float32)
+    cols = slice(0, D) if xyz_last else slice(3, 3 + D)
+    want = np.zeros((B, N, D))
+    np.add.at(want, (np.arange(B)[:, None, None], idx.astype(np.int64)), go[..., cols].astype(np.float64))
+    scale = np.abs(want).max()
+
+    def run():
+        feats = torch.zeros(B, N, D, device="cuda", requires_grad=True)
+        ops.GroupPoints.apply(xyz, new_xyz, feats, dev(idx), xyz_last).backward(dev(go))
+        return feats.grad.clone()
+
+    monkeypatch.setenv("PN2_GROUP_GRAD_GROUPS", "1")              # the group kernel whatever the number of groups
+    a = run()
+    assert np.abs(a.cpu().numpy().astype(np.float64) - want).max() <= 2e-5 * scale
+    monkeypatch.delenv("PN2_GROUP_GRAD_GROUPS")
+    monkeypatch.setenv("PN2_GROUP_GRAD_ROWS", "1")
+    c = run()
+    assert np.abs(c.cpu().numpy().astype(np.float64) - want).max() <= 2e-5 * scale
