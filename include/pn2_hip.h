@@ -406,6 +406,22 @@ void pn2_prof_enable(int on);
 int pn2_prof_collect(char *names_buf, size_t names_cap, double *total_ms, long long *calls, double *bytes,
                      double *flops, int max_groups);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Point-cloud serialization        replaces Modules/PointTransformerV3/serialization (default.py:8-40 encode / decode,
+ *   z_order.py:86-125, hilbert.py:91-302), the first stage of Point.serialization (PointTransformerV3/blocks.py:98-150).
+ *   grid_coord [N][3] int32 (element strides gs between points, gc between coordinates), batch [N] int64 or NULL,
+ *   1 <= depth <= 16 (the reference's own limit, blocks.py:126); only the low `depth` bits of a coordinate count.
+ *   out_codes [n_orders][N] int64: one row per requested order, code = batch << 3 depth | curve key.
+ *   decode: order PN2_ORDER_Z or PN2_ORDER_HILBERT (like the reference); out_grid [N][3] int64, out_batch [N] or NULL. */
+#define PN2_ORDER_Z 0
+#define PN2_ORDER_Z_TRANS 1
+#define PN2_ORDER_HILBERT 2
+#define PN2_ORDER_HILBERT_TRANS 3
+int pn2_serialize_encode_i64(const int32_t *grid_coord, int64_t gs, int64_t gc, const int64_t *batch, long long N,
+                             int depth, const int32_t *orders, int n_orders, int64_t *out_codes, void *stream);
+int pn2_serialize_decode_i64(const int64_t *codes, long long N, int depth, int order, int64_t *out_grid,
+                             int64_t *out_batch, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,5 +33,6 @@ echo "pmc done"
 cd $R
 timeout -k 10 600 python tools/bench_features.py > $O/bench_features.json 2>> $O/bench.err
 timeout -k 10 300 python tools/bench_datapath.py > $O/bench_datapath.json 2>> $O/bench.err
+timeout -k 10 300 python tools/bench_serialization.py > $O/bench_serialization.json 2>> $O/bench.err
 echo "secondary benches done"
 ls -la $O
