@@ -974,7 +974,7 @@ __global__ __launch_bounds__(kXT) void fps_multi_kernel(const float* __restrict_
 // relative error < 2^-21.4 of the exact value and so does the box distance, hence the skip requires
 // box_distance * (1 - 2^-19) >= max d; non-finite values fail the comparison and are treated as "touched".
 // The ordering kernels: workgroups of kOT threads, kOP points per thread (loads of a thread are independent: all in flight).
-constexpr int kOT = 1024, kOP = 8;
+constexpr int kOT = 1024, kOP = 4;   // 262 144 points: 8 per thread 38 us for the three kernels, 4: 31 us, 2: 32 us
 
 // box[b] = {max enc(x), max enc(y), max enc(z), max ~enc(x), max ~enc(y), max ~enc(z)} (zeroed by the workspace memset);
 // one atomic per workgroup and value (same-address atomics retire one at a time)
