@@ -52,6 +52,19 @@ def rasterize_clouds(data_paths, json_path, raster_size, stride, store_metadata)
     return n_rasters
 
 
+def cloud_columns(data):
+    """The column convention of the reference's __getitem__ (:206-218) for a cloud in memory: an xyz-only cloud is padded
+    with eight ZERO columns first, then columns are xyz | offset(3) | cylinder id | features...
+    -> (points [N,3], offsets [N,3], features [N,F]) float32 on the current device.  The ONE definition of "features of a
+    cloud": the dataset path and predict.predict_tree both go through here."""
+    data = np.asarray(data)
+    if data.shape[1] == 3:
+        data = np.hstack((data, np.zeros((data.shape[0], 8), dtype=data.dtype)))
+    dev = torch.device("cuda", torch.cuda.current_device())
+    full = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)).to(dev)
+    return full[:, :3], full[:, 3:6], full[:, 7:]
+
+
 class RasterizedTreeSet_Hierarchical(Dataset):
     def __init__(self, paths, training=True, logger=None, data_augmentations=None, noise_distance=0.05, minibatch_size=20,
                  single_sample=False, raster_size=1.0, stride=1.0):
@@ -83,11 +96,7 @@ class RasterizedTreeSet_Hierarchical(Dataset):
     def from_array(self, data):
         """The body of the reference's __getitem__ (:201-268) for a cloud that is already in memory: columns
         xyz | offset(3) | cylinder id | features..."""
-        if data.shape[1] == 3:
-            data = np.hstack((data, np.zeros((data.shape[0], 8), dtype=data.dtype)))
-        dev = torch.device("cuda", torch.cuda.current_device())
-        full = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)).to(dev)
-        points, offsets, features = full[:, :3], full[:, 3:6], full[:, 7:]
+        points, offsets, features = cloud_columns(data)
         norms = offsets.norm(dim=1)
         return {"points": points, "features": features, "offset_mask": norms <= self.noise_distance,
                 "cloud_length": len(data), "offset_labels": offsets.contiguous(), "semantic_labels": (norms > self.noise_distance).long()}

@@ -213,6 +213,27 @@ class PointNet2(nn.Module):
         return z((n, 2)), z((n, 3)), z((n, 1)), z((n, 1))
 
     @staticmethod
+    def _scatter_minibatch(total, count, ids, values, differentiable=False):
+        """The reference's `total[ids] += values; count[ids] += 1` (lines 272-276, 376-380) for ONE mini-batch.  With
+        overlapping rasters an id occurs more than once in `ids`, and that expression is an index_put WITHOUT accumulation:
+        one duplicate lands (the last one on the CPU; on a GPU whichever store comes last) and the count goes up by one.
+        Done here deterministically: the last occurrence lands (streaming.last_occurrence) -- unless PN2_OVERLAP=average.
+        differentiable: returns the new `total` with the autograd history the reference's expression has."""
+        if streaming.overlap_mode() == "average" or ids.numel() == 0:
+            if differentiable:
+                total = total.index_add(0, ids, values)
+            else:
+                total.index_add_(0, ids, values)
+            count.index_add_(0, ids, torch.ones(ids.numel(), 1, dtype=count.dtype, device=count.device))
+            return total
+        keep, cnt = streaming.last_occurrence(ids, total.shape[0])
+        count.index_add_(0, ids, keep.to(count.dtype).unsqueeze(1))
+        if not differentiable:
+            total.index_add_(0, ids, values * keep.to(values.dtype).unsqueeze(1))
+            return total
+        return streaming.RefPut.apply(total, ids, values, keep, cnt)
+
+    @staticmethod
     def _average(total, count):
         seen = count.squeeze(1) > 0
         total[seen] /= count[seen]
@@ -262,10 +283,8 @@ class PointNet2(nn.Module):
             total_dev = torch.zeros((), dtype=torch.float64, device=device)
         for mini_batch in batch["mini_batches"]:
             sem, off, ids, ids_off = self._predict_minibatch(mini_batch)
-            sem_sum[ids] += sem.detach()
-            off_sum[ids_off] += off.detach()
-            sem_cnt[ids] += 1
-            off_cnt[ids_off] += 1
+            self._scatter_minibatch(sem_sum, sem_cnt, ids, sem.detach())
+            self._scatter_minibatch(off_sum, off_cnt, ids_off, off.detach())
             if return_loss:
                 sem_lab = sem_all.index_select(0, ids)
                 off_lab = off_all.index_select(0, ids_off)
@@ -302,10 +321,8 @@ class PointNet2(nn.Module):
         sem_sum, off_sum, sem_cnt, off_cnt = self._accumulators(batch["cloud_length"], "cuda")
         for mini_batch in batch["mini_batches"]:
             sem, off, ids, ids_off = self._predict_minibatch(mini_batch)
-            sem_sum[ids] += sem
-            off_sum[ids_off] += off
-            sem_cnt[ids] += 1
-            off_cnt[ids_off] += 1
+            sem_sum = self._scatter_minibatch(sem_sum, sem_cnt, ids, sem, differentiable=True)
+            off_sum = self._scatter_minibatch(off_sum, off_cnt, ids_off, off, differentiable=True)
         output = {"semantic_prediction_logits": self._average(sem_sum, sem_cnt),
                   "offset_predictions": self._average(off_sum, off_cnt)}
         if return_loss:

@@ -30,6 +30,20 @@ class MLPLayer(ctypes.Structure):
 
 
 _lp = ctypes.POINTER(MLPLayer)
+WGRAD_TASKS_MAX = 64                 # PN2_WGRAD_TASKS_MAX
+
+
+class WgradTask(ctypes.Structure):
+    """struct pn2_wgrad_task: one deferred split-K slab reduction (slab [nsplit][mn] -> out [mn] +=)."""
+    _fields_ = [("slab", _vp), ("out", _vp), ("mn", ctypes.c_int64), ("nsplit", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+class WgradTasks(ctypes.Structure):
+    """struct pn2_wgrad_tasks: the HOST list a chain backward appends its deferred reductions to."""
+    _fields_ = [("n", ctypes.c_int32), ("reserved", ctypes.c_int32), ("t", WgradTask * WGRAD_TASKS_MAX)]
+
+
+_tp = ctypes.POINTER(WgradTasks)
 
 
 class Segments(ctypes.Structure):
@@ -97,9 +111,9 @@ SIGNATURES = {
     "pn2_mlp_workspace_bytes": (_sz, [_int, _lp, _int, _int]),
     "pn2_mlp_chain_fwd_f32": (_int, [_vp, _i64, _int, _lp, _int, _int, _int, _vp, _vp, _sp, _int, _vp, _sz, _vp]),
     "pn2_mlp_link_partial_bytes": (_sz, [_int, _int, _int, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
-    "pn2_mlp_flush_wgrad": (_int, [_vp]),
-    "pn2_mlp_drop_wgrad": (_int, []),
-    "pn2_mlp_chain_bwd_f32": (_int, [_vp, _i64, _int, _lp, _int, _int, _vp, _vp, _vp, _i64, _int, _vp, _vp, _sp, _int, _vp, _sz, _vp]),
+    "pn2_mlp_reduce_wgrad": (_int, [ctypes.POINTER(WgradTask), _int, _vp]),
+    "pn2_mlp_chain_bwd_f32": (_int, [_vp, _i64, _int, _lp, _int, _int, _vp, _vp, _vp, _i64, _int, _vp, _vp, _sp, _int, _tp, _vp, _sz,
+                                     _vp]),
     "pn2_cylinder_project_f32": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _vp]),
     "pn2_raster_ranges_f32": (_int, [_vp, _i64, _int, _vp, _int, _int, _int, _vp, _vp, _vp]),
     "pn2_raster_keys": (_int, [_vp, _vp, _int, _int, _int, _vp, _vp]),
@@ -117,9 +131,8 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 3                      # PN2_ABI_VERSION of include/pn2_hip.h
+ABI_VERSION = 4                      # PN2_ABI_VERSION of include/pn2_hip.h
 CHAIN_ACCUMULATE_DX = 0x100          # PN2_CHAIN_ACCUMULATE_DX
-CHAIN_DEFER_WGRAD = 0x200            # PN2_CHAIN_DEFER_WGRAD
 CHAIN_LAZY_OUT = 0x400               # PN2_CHAIN_LAZY_OUT
 CHAIN_ZERO_LEAD = 0x800              # PN2_CHAIN_ZERO_LEAD
 STATUS_FPS_HANDOFF, STATUS_FPS_ARRIVAL, STATUS_BAD_INDEX = 1, 2, 4   # PN2_STATUS_* bits

@@ -517,7 +517,9 @@ extern "C" int pn2_ball_query_cells_f32(const float* xyz, int64_t sb, int64_t sn
     const int Keff = nsample < N ? nsample : N;
     const long long waves = (long long)B * S;
     if (waves > 0x7FFFFFFFll) return PN2_E_BADARG;
-    PN2_LAUNCH("ball_query", (double)B * (12.0 * N + 12.0 * S + 8.0 * S * Keff), 8.0 * B * (double)S * N, ball_query_cells_kernel,
+    // flops = 0: the cell search does not run the S x N distance tests of the index walk (its candidate count is data
+    // dependent), so a "brute-force equivalent" rate would be a meaningless number in the profile; the HBM figure stays
+    PN2_LAUNCH("ball_query", (double)B * (12.0 * N + 12.0 * S + 8.0 * S * Keff), 0, ball_query_cells_kernel,
                dim3((unsigned)waves), dim3(kBlock), (hipStream_t)stream, xyz, sb, sn, sc, new_xyz, qb, qn, qc, B, N, S, r2,
                Keff, box, (const int*)cellstart, (const int*)order, sorted_xyz, out_idx);
     PN2_LAUNCH_CHECK();

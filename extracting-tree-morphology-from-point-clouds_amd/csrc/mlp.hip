@@ -22,9 +22,6 @@
 //                                                                    fixed-order slab sum -> deterministic)
 #include <stdlib.h>
 
-#include <mutex>
-#include <vector>
-
 #include "pn2_common.h"
 #include <cstdlib>
 
@@ -221,6 +218,7 @@ struct GemmArgs {
     const float* ecoef;
     int erelu;
     long long pstride;    // partial layout: 0 = [chunk][2][N] (row-major); else channel-major, column c at c * pstride + 2 * chunk
+    int precision;        // host side only: PN2_PRECISION_* of the 128-tile contraction (travels with the call, no global state)
     int accumulate;       // EPI_STORE: C += result (PN2_CHAIN_ACCUMULATE_DX): the accumulators START from C -- the loads
                           // travel with the first K-tile's instead of forming a read-modify-write chain in the epilogue
 };
@@ -1485,11 +1483,6 @@ inline void add_slab_task(SlabTasks& T, const float* slab, int nsplit, long long
     t.slab = slab, t.out = out, t.mn = mn, t.nsplit = nsplit, t.first_block = T.blocks;
     T.blocks += (int)((mn + 63) / 64);
 }
-// Deferred reductions (PN2_CHAIN_DEFER_WGRAD): the tasks of every chain backward of a pass, launched together by
-// pn2_mlp_flush_wgrad.  Process-wide (the autograd engine calls the chains from its own threads).
-std::mutex g_pending_mutex;
-std::vector<SlabTask> g_pending;
-
 inline void flush_slab_tasks(SlabTasks& T, hipStream_t s) {
     if (!T.n) return;
     double bytes = 0.0;
@@ -1568,14 +1561,10 @@ int launch_gemm_tv(GemmArgs& g, const Segs& S, hipStream_t s, int* nblk_out) {
 
 inline long long grid_blocks(int M, int N, int tile) { return (long long)pn2::ceil_div(M, tile) * pn2::ceil_div(N, tile); }
 
-// process-wide precision of the 128-tile contractions for the calls in flight on this thread (set by the chain entry
-// points from their `precision` argument; the small-problem tiles always run fp32)
-thread_local int t_precision = PN2_PRECISION_F32;
-
 template <bool A_T, int A_KIND, bool B_T, int B_KIND, int EPI>
 int launch_gemm(GemmArgs& g, const Segs& S, int tile, hipStream_t s, int* nblk_out = nullptr) {
     const bool vec = vec_ok(g.A) && vec_ok(g.B);
-    if (tile == 128 && t_precision == PN2_PRECISION_BF16 && vec)
+    if (tile == 128 && g.precision == PN2_PRECISION_BF16 && vec)   // the small-problem tiles always run fp32
         return launch_gemm_tv<A_T, A_KIND, B_T, B_KIND, EPI, 128, true, 1, true>(g, S, s, nblk_out);
     if (tile == 128)
         return vec ? launch_gemm_tv<A_T, A_KIND, B_T, B_KIND, EPI, 128, true>(g, S, s, nblk_out)
@@ -1806,7 +1795,6 @@ extern "C" int pn2_mlp_chain_fwd_f32(const float* x, int64_t ldx, int rows, cons
         return PN2_E_BADARG;
     if (lazy_out && (pool_k > 1 || !layers[nlayers - 1].has_bn)) return PN2_E_BADARG;
     if (precision != PN2_PRECISION_F32 && precision != PN2_PRECISION_BF16) return PN2_E_BADARG;
-    t_precision = precision;
     if (!segs_valid(rows, segments, pool_k)) return PN2_E_BADARG;
     const Segs S = make_segs(rows, training ? segments : nullptr);   // eval mode: one coefficient block serves every row
     if (workspace_bytes < pn2_mlp_workspace_bytes(rows, layers, nlayers, S.nseg) || !workspace) return PN2_E_WORKSPACE;
@@ -1822,6 +1810,7 @@ extern "C" int pn2_mlp_chain_fwd_f32(const float* x, int64_t ldx, int rows, cons
         float* y = direct_out ? out : L.y;
         if (!y || (L.has_bn && !L.stats)) return PN2_E_BADARG;
         GemmArgs g{};
+        g.precision = precision;
         g.A = act_operand(in, rows, L.cin);
         g.B = plain(L.weight, L.cin, L.cout, L.cin);
         g.M = rows;
@@ -1882,17 +1871,18 @@ extern "C" int pn2_mlp_chain_fwd_f32(const float* x, int64_t ldx, int rows, cons
 extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, const pn2_mlp_layer* layers, int nlayers,
                                      int pool_k, const float* dout, const int32_t* pool_arg, float* dx, int64_t lddx,
                                      int dx_first_col, float* scratch_a, float* scratch_b, const pn2_segments* segments,
-                                     int precision, void* workspace, size_t workspace_bytes, void* stream) {
+                                     int precision, pn2_wgrad_tasks* deferred, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
     if (!x || !layers || nlayers <= 0 || rows <= 0 || !dout || !scratch_a || !scratch_b) return PN2_E_BADARG;
     if (dx_first_col < 0 || dx_first_col >= layers[0].cin) return PN2_E_BADARG;
     const int accumulate_dx = (precision & PN2_CHAIN_ACCUMULATE_DX) ? 1 : 0;
-    const bool defer_wgrad = (precision & PN2_CHAIN_DEFER_WGRAD) != 0;
+    // deferred reductions go to the caller's list (pn2_hip.h); a list without room makes this call reduce in place
+    const bool defer_wgrad = deferred && deferred->n >= 0 && deferred->n + nlayers <= PN2_WGRAD_TASKS_MAX;
     bool zero_lead = (precision & PN2_CHAIN_ZERO_LEAD) != 0 && dx && dx_first_col > 0;
     if (zero_lead && accumulate_dx) return PN2_E_BADARG;
-    precision &= ~(PN2_CHAIN_ACCUMULATE_DX | PN2_CHAIN_DEFER_WGRAD | PN2_CHAIN_ZERO_LEAD);
+    precision &= ~(PN2_CHAIN_ACCUMULATE_DX | PN2_CHAIN_ZERO_LEAD);
     if (precision != PN2_PRECISION_F32 && precision != PN2_PRECISION_BF16) return PN2_E_BADARG;
     if (accumulate_dx && !dx) return PN2_E_BADARG;
-    t_precision = precision;
     if (!segs_valid(rows, segments, pool_k)) return PN2_E_BADARG;
     const Segs S = make_segs(rows, segments);
     if (workspace_bytes < pn2_mlp_workspace_bytes(rows, layers, nlayers, S.nseg) || !workspace) return PN2_E_WORKSPACE;
@@ -2026,6 +2016,7 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
         if (L.dweight) {
             const WgradPlan wp = plan_wgrad(rows, L.cout, L.cin, S.nseg);
             GemmArgs g{};
+            g.precision = precision;
             g.A = dy;                       // [rows = K][cout = M], direct layout
             g.B = act_operand(in, rows, L.cin);
             g.M = L.cout;
@@ -2062,6 +2053,7 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
             float* target = i > 0 ? bufs[which] : dx + skip;
             const long long ldt = i > 0 ? L.cin : lddx;
             GemmArgs g{};
+            g.precision = precision;
             g.A = dy;                       // [rows = M][cout = K]
             g.B = plain(L.weight + skip, L.cin, L.cout, L.cin - skip);   // [cout = K][cin = N], direct layout
             g.M = rows;
@@ -2098,8 +2090,10 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
         }
     }
     if (defer_wgrad) {
-        std::lock_guard<std::mutex> lock(g_pending_mutex);
-        for (int i = 0; i < tasks.n; ++i) g_pending.push_back(tasks.t[i]);
+        for (int i = 0; i < tasks.n; ++i) {
+            pn2_wgrad_task& t = deferred->t[deferred->n++];
+            t.slab = tasks.t[i].slab, t.out = tasks.t[i].out, t.mn = tasks.t[i].mn, t.nsplit = tasks.t[i].nsplit, t.reserved = 0;
+        }
     } else {
         flush_slab_tasks(tasks, s);
     }
@@ -2107,8 +2101,6 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
     return 0;
 }
 
-// The weight-gradient reductions of every pn2_mlp_chain_bwd_f32 call made with PN2_CHAIN_DEFER_WGRAD since the last flush,
-// in as few launches as the task table allows (32 tasks each).  The workspaces of those calls must still be alive.
 extern "C" size_t pn2_mlp_link_partial_bytes(int rows, int cin, int nseg, int32_t* block_rows, int32_t* chunks_per_block) {
     if (rows <= 0 || cin <= 0) return 0;
     if (nseg < 1) nseg = 1;
@@ -2117,15 +2109,15 @@ extern "C" size_t pn2_mlp_link_partial_bytes(int rows, int cin, int nseg, int32_
     return ((size_t)pn2::ceil_div(rows, 32) + 2 * (size_t)nseg) * 2 * (size_t)cin * sizeof(float);
 }
 
-extern "C" int pn2_mlp_flush_wgrad(void* stream) {
-    std::vector<SlabTask> todo;
-    {
-        std::lock_guard<std::mutex> lock(g_pending_mutex);
-        todo.swap(g_pending);
-    }
+// The reductions pn2_mlp_chain_bwd_f32 calls left in their callers' lists (`deferred`), in as few launches as the task table
+// allows (SLAB_TASKS each).  The workspaces of those calls must still be alive.  Stateless: everything arrives by argument.
+extern "C" int pn2_mlp_reduce_wgrad(const pn2_wgrad_task* tasks, int n, void* stream) {
+    if (n < 0 || (n > 0 && !tasks)) return PN2_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
     SlabTasks T{};
-    for (const SlabTask& t : todo) {
+    for (int k = 0; k < n; ++k) {
+        const pn2_wgrad_task& t = tasks[k];
+        if (!t.slab || !t.out || t.mn <= 0 || t.nsplit <= 0) return PN2_E_BADARG;
         // two reductions into the SAME gradient (a layer that ran more than once in this backward pass: the mini-batches of
         // forward_hierarchical) must not share a launch -- their blocks would read-modify-write the same elements
         bool clash = T.n == SLAB_TASKS;
@@ -2135,12 +2127,5 @@ extern "C" int pn2_mlp_flush_wgrad(void* stream) {
     }
     flush_slab_tasks(T, s);
     PN2_LAUNCH_CHECK();
-    return (int)todo.size();
-}
-// forget them instead (a backward pass that died half way)
-extern "C" int pn2_mlp_drop_wgrad(void) {
-    std::lock_guard<std::mutex> lock(g_pending_mutex);
-    const int n = (int)g_pending.size();
-    g_pending.clear();
-    return n;
+    return 0;
 }

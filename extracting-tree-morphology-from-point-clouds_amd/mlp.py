@@ -8,8 +8,9 @@ and hand their layers to ``chain_rows``; one C-ABI call runs the whole chain for
 (include/pn2_hip.h: pn2_mlp_chain_{fwd,bwd}_f32).
 """
 import ctypes
-
+import functools
 import os
+import threading
 
 import torch
 
@@ -192,8 +193,11 @@ class _ChainFn(torch.autograd.Function):
         ws = torch.empty(lib.pn2_mlp_workspace_bytes(rows, arr, n, ctx.nseg), dtype=torch.uint8, device=dev)
         flops = 4 * rows * sum(int(a.cin) * int(a.cout) for a in arr)
         nbytes = 4 * rows * (cin0 + 5 * sum(int(a.cout) for a in arr))
-        if _DeferredWgrad.enlist(ws):
-            flags |= _hip.CHAIN_DEFER_WGRAD
+        # Deferral is safe only when every weight-gradient target of this call is the parameter's OWN .grad buffer (nothing is
+        # returned to autograd for it): a returned tensor would be read by AccumulateGrad / summed with other uses of the
+        # weight BEFORE the end-of-pass reduction has written into it.
+        targets_are_grad_buffers = all(g is None for g in grads[0::4])
+        deferred = _DeferredWgrad.enlist(ws) if targets_are_grad_buffers else None
         # linked chains: BatchNorm-backward column sums handed from the consumer's dgrad epilogue to the producer
         handed = (meta.get("lazy_handle") or {}).pop("partial", None)
         if handed is not None:                            # this chain produced a LazyRows and its consumer did the sums
@@ -212,20 +216,23 @@ class _ChainFn(torch.autograd.Function):
             arr[0].in_partial = None
         _hip.call("mlp_chain_bwd", lib.pn2_mlp_chain_bwd_f32, x.data_ptr(), x.stride(0), rows, arr, n, int(meta["pool_k"]),
                   dout.data_ptr(), _hip.ptr(arg), _hip.ptr(dx), cin0, skip, sa.data_ptr(), sb.data_ptr(), seg_ptr, flags,
-                  ws.data_ptr(), ws.numel(), _hip.stream_ptr(), nbytes=nbytes, flops=flops)
+                  deferred, ws.data_ptr(), ws.numel(), _hip.stream_ptr(), nbytes=nbytes, flops=flops)
         if emit is not None:
             link.handle["partial"] = emit
         return (dx, None, *grads)
 
 
 class _DeferredWgrad:
-    """Weight-gradient slab reductions of a whole backward pass in one launch (PN2_CHAIN_DEFER_WGRAD): every chain backward
-    leaves its slabs in its workspace, the reductions run from an autograd-engine callback when the pass has finished --
-    before loss.backward() returns, so nobody sees a weight gradient without them.  The workspaces are kept alive here
-    until then.  Passes are told apart by the engine's graph-task id: reductions left behind by a pass that died are
-    dropped when the next one starts.  PN2_NO_DEFER_WGRAD=1 reduces per chain call."""
-    task_id = None
-    workspaces = []
+    """Weight-gradient slab reductions of a whole backward pass in as few launches as possible: every chain backward appends
+    the reductions it owes to a host list (pn2_wgrad_tasks, include/pn2_hip.h) and leaves its slabs in its workspace; the
+    reductions run from an autograd-engine callback when the pass has finished -- before loss.backward() returns, so nobody
+    sees a weight gradient without them.  One record PER BACKWARD PASS (keyed by the engine's graph-task id) and device: a
+    nested or re-entrant backward (checkpointing, a backward inside a hook) has its own list and its own callback and never
+    touches the outer pass's.  The library itself holds no state.  A pass that died leaves its record behind; records are few
+    (the workspaces they pin are dropped when more than MAX_LIVE passes are pending).  PN2_NO_DEFER_WGRAD=1 reduces per call."""
+    MAX_LIVE = 8
+    _lock = threading.Lock()
+    _passes = {}          # (graph task id, device index) -> {"lists": [WgradTasks], "keep": [workspaces], "stream": ptr}
 
     @classmethod
     def enabled(cls):
@@ -233,31 +240,43 @@ class _DeferredWgrad:
 
     @classmethod
     def enlist(cls, ws):
-        """-> True when the calling chain backward may defer (we are inside a backward pass and a flush is queued)."""
+        """-> ctypes pointer to the list the calling chain backward appends to, or None (reduce inside the call)."""
         if not cls.enabled():
-            return False
+            return None
         tid = torch._C._current_graph_task_id()
         if tid < 0:
-            return False
-        if tid != cls.task_id:
-            if cls.task_id is not None or cls.workspaces:
-                _hip.lib().pn2_mlp_drop_wgrad()
-                cls.workspaces = []
-            torch.autograd.Variable._execution_engine.queue_callback(cls.flush)
-            cls.task_id = tid
-        cls.workspaces.append(ws)
-        return True
+            return None
+        key = (tid, ws.device.index)
+        with cls._lock:
+            rec = cls._passes.get(key)
+            if rec is None:
+                while len(cls._passes) >= cls.MAX_LIVE:          # leftovers of passes that died
+                    cls._passes.pop(next(iter(cls._passes)))
+                rec = cls._passes[key] = {"lists": [_hip.WgradTasks()], "keep": [], "stream": _hip.stream_ptr()}
+                torch.autograd.Variable._execution_engine.queue_callback(functools.partial(cls.flush, key))
+            if rec["lists"][-1].n > _hip.WGRAD_TASKS_MAX - 8:    # room for the longest chain
+                rec["lists"].append(_hip.WgradTasks())
+            rec["keep"].append(ws)
+            return ctypes.pointer(rec["lists"][-1])
 
     @classmethod
-    def flush(cls):
-        try:
-            if cls.workspaces:
-                st = _hip.lib().pn2_mlp_flush_wgrad(_hip.stream_ptr())
-                if st < 0:
-                    raise RuntimeError(f"pn2_mlp_flush_wgrad -> {st}")
-        finally:
-            cls.workspaces = []
-            cls.task_id = None
+    def flush(cls, key):
+        with cls._lock:
+            rec = cls._passes.pop(key, None)
+        if rec is None:
+            return
+        n = sum(int(L.n) for L in rec["lists"])
+        if n == 0:
+            return
+        arr = (_hip.WgradTask * n)()
+        k = 0
+        for L in rec["lists"]:
+            for i in range(int(L.n)):
+                arr[k] = L.t[i]
+                k += 1
+        st = _hip.lib().pn2_mlp_reduce_wgrad(arr, n, rec["stream"])
+        if st != 0:
+            raise RuntimeError(f"pn2_mlp_reduce_wgrad -> {st}")
 
 
 class _Sub:

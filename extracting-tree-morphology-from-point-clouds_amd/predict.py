@@ -12,18 +12,23 @@ import numpy as np
 import torch
 
 from . import Projection, parallel, rasters
+from .DataLoading.RasterizedTreeSet import cloud_columns
 
 
 def predict_tree(model_offset, model_noise, cloud, raster_size=1.0, stride=1.0, minibatch_size=60, cylinders=None):
-    """cloud: float array [N, >=3] (xyz, then optional label / feature columns as in the 11-column label files; columns
-    7: are the network features, missing ones default to the reference's dummy ones).  -> dict of numpy arrays."""
+    """cloud: float array [N, 3] or [N, >=8] (xyz, then the label / feature columns of the 11-column label files; columns
+    7: are the network features).  An xyz-only cloud gets the reference dataset's padding -- eight ZERO columns
+    (RasterizedTreeSet.py:207-211), i.e. zero features -- through the same code as the dataset path
+    (DataLoading.RasterizedTreeSet.cloud_columns), so a cloud predicts the same either way.
+    -> dict of numpy arrays."""
     dev = torch.device("cuda", torch.cuda.current_device())
     data = np.asarray(cloud)
+    if data.shape[1] != 3 and data.shape[1] < 8:
+        raise ValueError(f"predict_tree: a cloud has 3 columns (xyz) or at least 8 (xyz | offset | id | features...), got {data.shape[1]}")
     xyz64 = np.ascontiguousarray(data[:, :3], dtype=np.float64)
-    pts = torch.from_numpy(xyz64.astype(np.float32)).to(dev)
     n = len(data)
-    feats = (torch.from_numpy(np.ascontiguousarray(data[:, 7:11], dtype=np.float32)).to(dev) if data.shape[1] >= 11
-             else torch.ones(n, 4, device=dev))
+    pts, _, feats = cloud_columns(data)                                 # the one definition of "features of a cloud"
+    pts, feats = pts.contiguous(), feats.contiguous()
     stream = rasters.build_stream(pts, feats, None, raster_size, stride, minibatch_size)
     batch = {"mini_batches": stream, "cloud_length": n}
     with torch.no_grad():

@@ -59,6 +59,7 @@ class RasterStream(list):
     """The mini-batches of one tree: a list of the reference's mini-batch dicts (coords [B,3,N], feats [B,F,N], masks_pad,
     masks_off, point_ids) whose tensors are VIEWS of flat whole-tree buffers, kept in `flat` for the fused pass."""
     flat = None
+    disjoint = False     # True: stride >= raster size, no point id repeats inside a mini-batch (streaming.py skips the overlap pass)
 
 
 def rasterize_points(points, raster_size=1.0, stride=1.0, bounds=None):
@@ -137,6 +138,7 @@ def build_stream(points, features, offset_mask, raster_size=1.0, stride=1.0, min
     stream.flat = {"xyz_cf": xyz_cf, "feats_cf": feats_cf, "masks_pad": mask, "point_ids": ids, "masks_off": moff,
                    "lengths": [t[1] for t in table], "rasters": len(lengths), "boxes": boxes, "dims": dims,
                    "bounds": bounds}
+    stream.disjoint = float(stride) >= float(raster_size)      # half-open boxes on a grid of pitch `stride`: no point in two
     return stream
 
 

@@ -19,9 +19,18 @@ super-batch:
     index_add (no boolean indexing, no host synchronisation before the final loss read-back).
 
 Same numbers as the sequential loop up to fp32 summation order (tests/test_streaming.py compares both with the
-reference's fixture).  Deviation, documented: when one point id occurs twice inside ONE mini-batch (overlapping rasters,
-stride < size), the reference's `sum[ids] += x` keeps an arbitrary one of the duplicates; here both are averaged.
+reference's fixture).
+
+Overlapping rasters (stride < size: the training default, train_PointNet2.py:84-85,109).  A point id then occurs more than
+once inside ONE mini-batch, and the reference's `avg[point_ids] += x; count[point_ids] += 1` (PointNet2.py:272-276) is an
+index_put WITHOUT accumulation: per mini-batch ONE of the duplicates is kept (the last one on the CPU, an arbitrary one on
+a GPU) and the count goes up by one.  Default here (PN2_OVERLAP=reference): exactly that, deterministically -- the last
+occurrence inside the mini-batch contributes, count + 1 per (id, mini-batch) -- including, in forward_hierarchical, the
+gradient the reference's expression implies (RefScatter below).  PN2_OVERLAP=average (opt-in) averages every occurrence
+instead (round 2's behaviour).  Pinned by tests/golden/streaming_overlap_d5.npz / hierarchical_overlap_d5.npz.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -193,23 +202,108 @@ def _valid_rows(layout, device):
     return rows, ids, moff, seg
 
 
+def overlap_mode():
+    mode = os.environ.get("PN2_OVERLAP", "reference")
+    if mode not in ("reference", "average"):
+        raise ValueError(f"PN2_OVERLAP={mode!r}: 'reference' (one contribution per id and mini-batch, PointNet2.py:272-276) or 'average'")
+    return mode
+
+
+def last_occurrence(keys, size, valid=None):
+    """-> (keep, count): keep[r] = row r is the LAST row (highest r) that carries keys[r] -- among the rows with valid[r]
+    when a mask is given -- which is what the reference's CPU `t[ids] += x` keeps of duplicate ids; count [size] int64 =
+    number of (valid) rows per key.  keys int64 in [0, size)."""
+    dev = keys.device
+    pos = torch.arange(keys.numel(), device=dev)
+    src = pos if valid is None else torch.where(valid, pos, torch.full_like(pos, -1))
+    last = torch.full((size,), -1, dtype=torch.long, device=dev).scatter_reduce_(0, keys, src, "amax", include_self=True)
+    keep = last.index_select(0, keys) == pos
+    ones = torch.ones_like(keys) if valid is None else valid.to(torch.long)
+    count = torch.zeros(size, dtype=torch.long, device=dev).index_add_(0, keys, ones)
+    return keep, count
+
+
+class RefScatter(torch.autograd.Function):
+    """Contribution rows of the reference's `t[ids] += v` over a stream of mini-batches (PointNet2.py:272-276, 376-380) as one
+    differentiable op: forward -> v * keep (the last duplicate of an id inside a mini-batch is the one that lands).
+    Backward = what autograd makes of the reference's expression (gather, add, NON-accumulating index_put per mini-batch):
+    every duplicate row receives the gradient of its id's accumulator entry, and the gradient that flows on to the
+    accumulator of EARLIER mini-batches is multiplied by the number of duplicates (the gather's backward adds once per
+    occurrence): row r of mini-batch j gets G[id] * prod over later mini-batches j' of max(1, occurrences of id in j')."""
+
+    @staticmethod
+    def forward(ctx, v, keep, mult):
+        ctx.save_for_backward(mult)
+        return v * keep.to(v.dtype).unsqueeze(1)
+
+    @staticmethod
+    def backward(ctx, g):
+        (mult,) = ctx.saved_tensors
+        return g * mult.unsqueeze(1), None, None
+
+
+class RefPut(torch.autograd.Function):
+    """ONE mini-batch of the reference's `t[ids] += v` with autograd history (forward_hierarchical, PointNet2.py:376-380),
+    mini-batch-by-mini-batch execution: forward t + scatter(v * keep); backward exactly what autograd derives for
+    `t.index_put_(ids, t[ids] + v)`: dv = G[ids] for EVERY occurrence, dt = G off the indexed entries and
+    (occurrences of the id) * G on them.  count: [n] occurrences per id (streaming.last_occurrence)."""
+
+    @staticmethod
+    def forward(ctx, t, ids, v, keep, count):
+        ctx.save_for_backward(ids, count)
+        return t.index_add(0, ids, v * keep.to(v.dtype).unsqueeze(1))
+
+    @staticmethod
+    def backward(ctx, g):
+        ids, count = ctx.saved_tensors
+        return g * count.clamp_min(1).to(g.dtype).unsqueeze(1), None, g.index_select(0, ids), None, None
+
+
+def _later_duplicates(count, seg, ids, M, n):
+    """mult[r] = prod_{j' > seg[r]} max(1, count[j', ids[r]]) (float32); count: [M * n] occurrences per (mini-batch, id)."""
+    d = count.view(M, n).clamp_min(1).to(torch.float32)
+    suffix = torch.flip(torch.cumprod(torch.flip(d, [0]), 0), [0])                # prod_{j' >= j}
+    after = torch.cat([suffix[1:], torch.ones(1, n, dtype=torch.float32, device=d.device)])
+    return after.view(-1).index_select(0, seg * n + ids)
+
+
 class _Accumulators:
     def __init__(self, n, device):
+        self.n = n
         self.sem = torch.zeros(n, 2, dtype=torch.float, device=device)
         self.off = torch.zeros(n, 3, dtype=torch.float, device=device)
         self.sem_cnt = torch.zeros(n, 1, dtype=torch.float, device=device)
         self.off_cnt = torch.zeros(n, 1, dtype=torch.float, device=device)
 
-    def add(self, ids, sem, off, moff, differentiable):
+    def add(self, ids, sem, off, moff, differentiable, seg=None, M=1, disjoint=False):
+        """ids / sem / off / moff: the valid rows of the pass, mini-batch after mini-batch; seg: their mini-batch number
+        (None: one mini-batch); disjoint: the caller knows that no id repeats inside a mini-batch (no overlap handling)."""
         m = moff.to(torch.float).unsqueeze(1)
+        if not disjoint and overlap_mode() == "reference" and ids.numel():
+            n = self.n
+            if M * n >= 2 ** 31:
+                raise RuntimeError("overlap handling: too many (mini-batch, point) pairs for one pass")
+            segv = torch.zeros_like(ids) if seg is None else seg
+            keys = segv * n + ids
+            ks, cs = last_occurrence(keys, M * n)
+            ko, co = last_occurrence(keys, M * n, moff)
+            if differentiable:
+                sem = RefScatter.apply(sem, ks, _later_duplicates(cs, segv, ids, M, n))
+                off = RefScatter.apply(off, ko, _later_duplicates(co, segv, ids, M, n) * m.squeeze(1))   # unmasked rows never enter
+            else:
+                sem, off = sem * ks.to(sem.dtype).unsqueeze(1), off * ko.to(off.dtype).unsqueeze(1)
+            ones, m_cnt = ks.to(torch.float).unsqueeze(1), ko.to(torch.float).unsqueeze(1)
+        else:
+            off = off * m
+            ones, m_cnt = torch.ones_like(m), m
         if differentiable:                  # forward_hierarchical keeps autograd history through the average
             self.sem = self.sem.index_add(0, ids, sem)
-            self.off = self.off.index_add(0, ids, off * m)
+            self.off = self.off.index_add(0, ids, off)
         else:
             self.sem.index_add_(0, ids, sem.detach())
-            self.off.index_add_(0, ids, off.detach() * m)
-        self.sem_cnt.index_add_(0, ids, torch.ones_like(m))
-        self.off_cnt.index_add_(0, ids, m)
+            self.off.index_add_(0, ids, off.detach())
+        self.sem_cnt.index_add_(0, ids, ones)
+        self.off_cnt.index_add_(0, ids, m_cnt)
 
     def average(self):
         return {"semantic_prediction_logits": self.sem / self.sem_cnt.clamp_min(1.0),
@@ -251,7 +345,8 @@ def run_tree(model, batch, return_loss, scaler=None, streaming=True):
         sem_rows, off_rows = backbone_and_heads(model, layout, device)
         rows, ids, moff, seg = _valid_rows(layout, device)
         sem, off = sem_rows.index_select(0, rows), off_rows.index_select(0, rows)
-        acc.add(ids, sem, off, moff, differentiable=return_loss and not streaming)
+        acc.add(ids, sem, off, moff, differentiable=return_loss and not streaming, seg=seg, M=layout.M,
+                disjoint=bool(getattr(stream, "disjoint", False)))
         if want_stream_loss:
             # per-mini-batch point_wise_loss (Loss.py:6-36) as segment means of per-row terms
             M = layout.M

@@ -31,7 +31,7 @@ extern "C" {
 #define PN2_E_BADARG (-1)   /* null pointer / non-positive size / unsupported size */
 #define PN2_E_WORKSPACE (-2) /* workspace too small */
 
-#define PN2_ABI_VERSION 3
+#define PN2_ABI_VERSION 4
 
 /* Bits of the caller-owned sticky STATUS word (a device int32 the caller zeroes once and reads at a synchronisation
  * point it has anyway, e.g. the loss read-back; the Python mirror: ops.check_status()).  A kernel ORs a bit in when it
@@ -331,13 +331,26 @@ typedef struct pn2_segments {
  * the semantic and the offset head on the backbone features, PointNet2.py:86-87 -- leave one gradient tensor behind
  * without a separate 3 x rows x cin x 4 byte add. */
 #define PN2_CHAIN_ACCUMULATE_DX 0x100
-/* pn2_mlp_chain_bwd_f32 only, OR-ed into `precision`: leave the weight-gradient slabs of this call in its workspace and
- * only REMEMBER their reduction; pn2_mlp_flush_wgrad(stream) then reduces the slabs of every such call since the last
- * flush in one launch (one launch per chain is 5-8 us of mostly latency, 12 of them per backward pass of the depth-4
- * model).  The caller keeps the workspaces alive until the flush and flushes before anything reads the weight gradients
- * (pn2_amd/mlp.py: an autograd-engine callback at the end of the backward pass).  pn2_mlp_drop_wgrad() forgets pending
- * reductions (a pass that died). */
-#define PN2_CHAIN_DEFER_WGRAD 0x200
+/* Deferred weight-gradient reductions.  The wgrad GEMMs of a chain backward leave split-K slabs in the call's workspace; one
+ * launch per chain to sum them is 5-8 us of mostly latency, 12 of them per backward pass of the depth-4 model.  With a
+ * non-NULL `deferred` (a HOST struct the caller owns) pn2_mlp_chain_bwd_f32 does not reduce: it APPENDS the reductions it
+ * owes (slab, nsplit, element count, target) to the list and returns; the caller keeps the call's workspace alive, and
+ * pn2_mlp_reduce_wgrad(tasks, n, stream) later performs any number of them in as few launches as possible (32 per launch;
+ * two reductions into the same target never share one) -- before anything reads the weight gradients (pn2_amd/mlp.py: an
+ * autograd-engine callback at the end of the backward pass, one list per backward pass).  The library keeps NO record of
+ * pending reductions: a pass that dies simply drops its list.  A list with fewer than nlayers free entries makes the call
+ * reduce in place instead. */
+#define PN2_WGRAD_TASKS_MAX 64
+typedef struct pn2_wgrad_task {
+    const float *slab; /* [nsplit][mn] */
+    float *out;        /* [mn], accumulated into */
+    int64_t mn;
+    int32_t nsplit, reserved;
+} pn2_wgrad_task;
+typedef struct pn2_wgrad_tasks {
+    int32_t n, reserved;
+    pn2_wgrad_task t[PN2_WGRAD_TASKS_MAX];
+} pn2_wgrad_tasks;
 /* pn2_mlp_chain_fwd_f32 only, OR-ed into `precision`: the last layer ends in a BatchNorm and its activation is NOT written
  * (`out` may be NULL): the consumer is a linked chain (pn2_mlp_layer.in_stats) that reads `y` and `stats` of that layer.
  * Saves one read and one write of rows x cout floats.  Not with pool_k > 1. */
@@ -354,10 +367,9 @@ int pn2_mlp_chain_fwd_f32(const float *x, int64_t ldx, int rows, const pn2_mlp_l
 int pn2_mlp_chain_bwd_f32(const float *x, int64_t ldx, int rows, const pn2_mlp_layer *layers, int nlayers,
                           int pool_k, const float *dout, const int32_t *pool_arg, float *dx, int64_t lddx,
                           int dx_first_col, float *scratch_a, float *scratch_b, const pn2_segments *segments,
-                          int precision, void *workspace, size_t workspace_bytes, void *stream);
+                          int precision, pn2_wgrad_tasks *deferred, void *workspace, size_t workspace_bytes, void *stream);
 size_t pn2_mlp_link_partial_bytes(int rows, int cin, int nseg, int32_t *block_rows, int32_t *chunks_per_block);
-int pn2_mlp_flush_wgrad(void *stream); /* -> number of reductions launched, or < 0 */
-int pn2_mlp_drop_wgrad(void);
+int pn2_mlp_reduce_wgrad(const pn2_wgrad_task *tasks, int n, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Closest-cylinder projection       replaces Modules/Projection.py:19-114 (closest_cylinder_cuda_batch; duplicated at

@@ -372,6 +372,7 @@ def _make_model(depth, n_real, n_pad, seed_t, centre):
 
 
 # --------------------------------------------------------------------------------------- streaming mode (a11)
+OVERLAP_FIRST = 0     # first raster of the overlapping-raster fixture (see make_streaming)
 class _FakeScaler:
     """GradScaler stand-in: scale(x) = x (the reference only calls scaler.scale(loss).backward() inside the model)."""
 
@@ -379,13 +380,27 @@ class _FakeScaler:
         return x
 
 
-def make_streaming():
+def overlap_rasters(xyz, size, stride, count=6, first=0):
+    """`count` consecutive rasters (x-major grid order, as the reference's rasteriser emits them) of at least 40 points."""
+    from pn2_amd.synthetic import rasterize
+    return [r for r in rasterize(xyz, size, stride) if len(r) >= 40][first:first + count]
+
+
+def make_streaming(size=2.0, stride=2.0, name="streaming_d5.npz", first=0):
     """forward_hierarchical_streaming (PointNet2.py:210-327) hard-codes device="cuda"; to run the REFERENCE's own
-    loop on this CPU-only host, "cuda" is mapped to "cpu" in torch.zeros / Tensor.to for the duration of the call."""
+    loop on this CPU-only host, "cuda" is mapped to "cpu" in torch.zeros / Tensor.to for the duration of the call.
+    size > stride: OVERLAPPING rasters (the training default, train_PointNet2.py:84-85,109: size 2.0, stride size / 2) --
+    a point id then occurs more than once inside one mini-batch and `avg[point_ids] += x` (PointNet2.py:272-276) keeps ONE
+    of the duplicates (on the CPU: the last one) with a count of 1."""
     helpers.load_pkg()
-    from pn2_amd.synthetic import gaussian_branch_tree, rasterize
+    from pn2_amd.synthetic import gaussian_branch_tree
     xyz, off, _ = gaussian_branch_tree(20000, seed=5)
-    rasters = [r for r in rasterize(xyz, 2.0, 2.0) if len(r) >= 40][:6]
+    rasters = overlap_rasters(xyz, size, stride, first=first)
+    if size > stride:
+        dup = [len(np.concatenate(rasters[k:k + 2])) - len(np.unique(np.concatenate(rasters[k:k + 2]))) for k in range(0, len(rasters), 2)]
+        allr = np.concatenate(rasters)
+        print(f"  {name}: duplicates inside the mini-batches {dup}, across the stream {len(allr) - len(np.unique(allr))}")
+        assert min(dup) > 0
     feats_all = sinpat((len(xyz), 4), 7)
     ids_all = np.concatenate(rasters)
     cloud_length = int(len(xyz))
@@ -455,12 +470,15 @@ def make_streaming():
     print(f"  streaming: reference fp32 vs float64 arithmetic: offsets {rel:.2e}, gradient norms {gn:.2e}")
     print("  streaming: FP boundary ties:", _fp_ties[0])
     assert _fp_ties[0] == 0
-    save("streaming_d5.npz", **out)
+    save(name, **out)
 
 
 if __name__ == "__main__":
     if "--only-streaming" in sys.argv:
         make_streaming()
+        raise SystemExit(0)
+    if "--only-overlap" in sys.argv:
+        make_streaming(2.0, 1.0, "streaming_overlap_d5.npz", first=OVERLAP_FIRST)
         raise SystemExit(0)
     make_streaming()
     make_ops()

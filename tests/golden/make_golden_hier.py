@@ -18,11 +18,11 @@ import make_golden as MG  # noqa: E402
 import torch  # noqa: E402
 
 
-def main():
+def main(size=2.0, stride=2.0, name="hierarchical_d5.npz", first=0):
     MG.helpers.load_pkg()
-    from pn2_amd.synthetic import gaussian_branch_tree, rasterize
+    from pn2_amd.synthetic import gaussian_branch_tree
     xyz, off, _ = gaussian_branch_tree(20000, seed=5)
-    rasters = [r for r in rasterize(xyz, 2.0, 2.0) if len(r) >= 40][:6]
+    rasters = MG.overlap_rasters(xyz, size, stride, first=first)
     feats_all = MG.sinpat((len(xyz), 4), 7)
     n = int(len(xyz))
     sem_lab = (np.arange(n) % 3 == 0).astype(np.int64)
@@ -74,9 +74,12 @@ def main():
     finally:
         torch.zeros, torch.Tensor.to = zeros, to
     assert MG._fp_ties[0] == 0
-    MG.save("hierarchical_d5.npz", **out)
+    MG.save(name, **out)
     print({k: (float(v) if np.ndim(v) == 0 else v.shape) for k, v in out.items()})
 
 
 if __name__ == "__main__":
-    main()
+    if "--overlap" in sys.argv:      # the training default: size 2.0, stride 1.0 (train_PointNet2.py:84-85,109)
+        main(2.0, 1.0, "hierarchical_overlap_d5.npz", first=MG.OVERLAP_FIRST)
+    else:
+        main()

@@ -50,3 +50,32 @@ def test_sharded_forest_prediction_equals_single_process():
         assert len(r["executed_cloud"]) == int((r["pred_full"][:, 6] == 0).sum())
         assert len(r["qsm_ids"]) == len(r["executed_cloud"]) and (r["qsm_ids"] // 100 == i).all()
         assert np.isfinite(r["qsm_offsets"]).all() and (r["qsm_distance"] >= 0).all()
+
+
+def test_xyz_only_cloud_predicts_the_same_through_predict_tree_and_the_dataset():
+    """An xyz-only cloud is padded with eight zero columns by the reference dataset (RasterizedTreeSet.py:207-211), i.e. its
+    network features are ZEROS; predict_tree must feed the same features as the dataset + forward_hierarchical_streaming path
+    (round-2 advisor finding: it fed ones)."""
+    helpers.load_pkg()
+    from pn2_amd import predict
+    from pn2_amd.DataLoading.RasterizedTreeSet import RasterizedTreeSet_Hierarchical
+    from pn2_amd.PointNet2.PointNet2 import PointNet2
+    from pn2_amd.synthetic import gaussian_branch_tree
+    xyz, _, _ = gaussian_branch_tree(6000, seed=77)
+    cloud = xyz.astype(np.float64)
+    torch.manual_seed(0)
+    model = PointNet2(depth=5).cuda().eval()
+    torch.manual_seed(5)
+    res = predict.predict_tree(model, model, cloud, minibatch_size=10)
+    ds = RasterizedTreeSet_Hierarchical([], training=False, minibatch_size=10)
+    item = ds.from_array(cloud)
+    assert item["features"].shape == (6000, 4) and not item["features"].any()
+    batch = ds.collate_fn_streaming([item])
+    torch.manual_seed(5)
+    with torch.no_grad():
+        noise = model.forward_hierarchical_streaming(batch, return_loss=False)["semantic_prediction_logits"]
+        out = model.forward_hierarchical_streaming(batch, return_loss=False)["offset_predictions"]
+    np.testing.assert_array_equal(res["pred_full"][:, 3:6], out.cpu().numpy().astype(np.float64))
+    np.testing.assert_array_equal(res["pred_full"][:, 6], torch.argmax(noise, 1).cpu().numpy().astype(np.float64))
+    with pytest.raises(ValueError):
+        predict.predict_tree(model, model, np.zeros((10, 5)))

@@ -674,7 +674,7 @@ def test_deferred_weight_gradients_and_head_pair(pn2):
             for layers in chains:
                 y = mlp.chain_rows(y, layers)
             (y * y).sum().backward()
-            assert _hip.lib().pn2_mlp_drop_wgrad() == 0, "weight-gradient reductions left pending after backward()"
+            assert not mlp._DeferredWgrad._passes, "weight-gradient reductions left pending after backward()"
         got[mode] = [p.grad.clone() for layers in chains for conv, bn, _ in layers for p in (conv.weight, bn.weight, bn.bias)]
     assert all(torch.equal(a, b) for a, b in zip(got["deferred"], got["per_chain"]))
     assert all(float(g.abs().max()) > 0 for g in got["deferred"])
@@ -692,7 +692,7 @@ def test_deferred_weight_gradients_and_head_pair(pn2):
         with env(**e):
             loss, _ = model(batch, return_loss=True)
             loss.backward()
-            assert _hip.lib().pn2_mlp_drop_wgrad() == 0
+            assert not mlp._DeferredWgrad._passes
         grads[mode] = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
     gmax = max(float(g.abs().max()) for g in grads["deferred"].values())
     for other in ("per_chain", "separate_heads"):
@@ -820,6 +820,89 @@ def test_three_nn_small_clouds_threads_per_point(pn2, monkeypatch, B, N, S):
 
 
 @pytest.mark.gpu
+def test_deferral_never_loses_a_returned_weight_gradient(pn2):
+    """Round-2 advisor finding: with mlp.FUSED_GRAD_ACCUMULATION = False (the documented switch for torch.autograd.grad-style
+    use) the chain backward RETURNS its weight gradients; a deferred slab reduction would then write into the returned tensor
+    after AccumulateGrad / the engine's input-buffer sum had already read it (zeros).  Deferral now happens only when every
+    target is the parameter's own .grad buffer.  Two accumulated backward() calls, a weight shared by two chains, and
+    torch.autograd.grad, each against PN2_NO_DEFER_WGRAD=1 -- bit for bit -- and against fused accumulation to rounding."""
+    import torch.nn as nn
+    from pn2_amd import mlp
+
+    def build():
+        torch.manual_seed(0)
+        mk = lambda ci, co: (nn.Conv1d(ci, co, 1).cuda(), nn.BatchNorm1d(co).cuda().train(), True)
+        return [mk(40, 64), mk(64, 64)], [mk(64, 32)]
+
+    xs = [torch.randn(6000, 40, device="cuda"), torch.randn(4000, 40, device="cuda")]
+
+    def params(chains):
+        return [p for layers in chains for conv, bn, _ in layers for p in (conv.weight, bn.weight, bn.bias)]
+
+    def run(fused, e):
+        a, b = build()
+        old = mlp.FUSED_GRAD_ACCUMULATION
+        mlp.FUSED_GRAD_ACCUMULATION = fused
+        try:
+            with env(**e):
+                for x in xs:                                  # two backward() calls accumulate; `a` is used by two chains
+                    h = mlp.chain_rows(x, a)
+                    loss = (mlp.chain_rows(h, b) ** 2).sum() + (mlp.chain_rows(x[:3000], a) ** 2).sum()
+                    loss.backward()
+                    assert not mlp._DeferredWgrad._passes
+                acc = [p.grad.clone() for p in params((a, b))]
+                ag = []
+                if not fused:                                 # (fused accumulation returns nothing to autograd.grad by design)
+                    h = mlp.chain_rows(xs[0], a)
+                    ag = torch.autograd.grad((mlp.chain_rows(h, b) ** 2).sum(), params((a, b)))
+        finally:
+            mlp.FUSED_GRAD_ACCUMULATION = old
+        return acc, list(ag)
+
+    ret_defer, ag_defer = run(False, {})
+    ret_plain, ag_plain = run(False, {"PN2_NO_DEFER_WGRAD": 1})
+    fused, _ = run(True, {})
+    for a, b in zip(ret_defer + ag_defer, ret_plain + ag_plain):
+        assert torch.equal(a, b)
+    assert all(float(g.abs().max()) > 0 for g in ret_defer + ag_defer)
+    for a, b in zip(ret_defer, fused):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+
+
+@pytest.mark.gpu
+def test_nested_backward_keeps_the_outer_pass_reductions(pn2):
+    """A backward pass started INSIDE another one (here: from a tensor hook) has its own graph-task id: its deferred
+    reductions are its own record and its own callback, the outer pass's pending reductions survive it (round-2 advisor:
+    a second task id used to be taken for a dead pass and the outer list dropped)."""
+    import torch.nn as nn
+    from pn2_amd import mlp
+    torch.manual_seed(0)
+    outer = [(nn.Conv1d(48, 64, 1).cuda(), nn.BatchNorm1d(64).cuda().train(), True), (nn.Conv1d(64, 64, 1).cuda(), nn.BatchNorm1d(64).cuda().train(), True)]
+    inner = [(nn.Conv1d(16, 32, 1).cuda(), nn.BatchNorm1d(32).cuda().train(), True)]
+    x, z = torch.randn(5000, 48, device="cuda"), torch.randn(3000, 16, device="cuda")
+
+    def run(nested):
+        for layers in (outer, inner):
+            for conv, bn, _ in layers:
+                conv.weight.grad = bn.weight.grad = bn.bias.grad = None
+        h = mlp.chain_rows(x, outer[:1])
+        if nested:
+            def hook(g):
+                with torch.enable_grad():
+                    (mlp.chain_rows(z, inner) ** 2).sum().backward()
+                return g
+            h.register_hook(hook)
+        (mlp.chain_rows(h, outer[1:]) ** 2).sum().backward()
+        assert not mlp._DeferredWgrad._passes
+        if not nested:
+            (mlp.chain_rows(z, inner) ** 2).sum().backward()
+        return [l[0].weight.grad.clone() for l in outer + inner]
+
+    for a, b in zip(run(True), run(False)):
+        assert torch.equal(a, b) and float(a.abs().max()) > 0
+
+
+@pytest.mark.gpu
 def test_layer_used_several_times_in_one_backward_pass(pn2):
     """forward_hierarchical runs the same layers once per mini-batch and calls backward() once: the deferred weight-gradient
     reductions of one layer then meet in the flush and must not share a launch (their blocks would read-modify-write the
@@ -839,7 +922,7 @@ def test_layer_used_several_times_in_one_backward_pass(pn2):
             with env(**e):
                 total = sum((mlp.chain_rows(x, layers) ** 2).sum() for x in xs)
                 total.backward()
-                assert _hip.lib().pn2_mlp_drop_wgrad() == 0
+                assert not mlp._DeferredWgrad._passes
             grads = [layers[0][0].weight.grad.clone(), layers[1][0].weight.grad.clone()]
             if mode in got:
                 assert all(torch.equal(a, b) for a, b in zip(grads, got[mode])), f"{mode}: run-to-run difference"
