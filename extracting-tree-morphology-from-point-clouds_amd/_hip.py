@@ -46,6 +46,14 @@ class WgradTasks(ctypes.Structure):
 _tp = ctypes.POINTER(WgradTasks)
 
 
+class Coop(ctypes.Structure):
+    """struct pn2_coop: cooperative chain launches (sync: >= 64 zeroed device uint32, one buffer per stream; status word)."""
+    _fields_ = [("sync", _vp), ("status", _vp), ("spin_limit", ctypes.c_uint32), ("max_workgroups", ctypes.c_int32)]
+
+
+_cp = ctypes.POINTER(Coop)
+
+
 class Segments(ctypes.Structure):
     """struct pn2_segments of include/pn2_hip.h: row_off is a HOST int32 array of nseg + 1 offsets."""
     _fields_ = [("nseg", ctypes.c_int32), ("row_off", ctypes.POINTER(ctypes.c_int32))]
@@ -109,11 +117,11 @@ SIGNATURES = {
     "pn2_prof_collect": (_int, [ctypes.c_char_p, _sz, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong),
                                 ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _int]),
     "pn2_mlp_workspace_bytes": (_sz, [_int, _lp, _int, _int]),
-    "pn2_mlp_chain_fwd_f32": (_int, [_vp, _i64, _int, _lp, _int, _int, _int, _vp, _vp, _sp, _int, _vp, _sz, _vp]),
+    "pn2_mlp_chain_fwd_f32": (_int, [_vp, _i64, _int, _lp, _int, _int, _int, _vp, _vp, _sp, _int, _cp, _vp, _sz, _vp]),
     "pn2_mlp_link_partial_bytes": (_sz, [_int, _int, _int, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "pn2_mlp_reduce_wgrad": (_int, [ctypes.POINTER(WgradTask), _int, _vp]),
-    "pn2_mlp_chain_bwd_f32": (_int, [_vp, _i64, _int, _lp, _int, _int, _vp, _vp, _vp, _i64, _int, _vp, _vp, _sp, _int, _tp, _vp, _sz,
-                                     _vp]),
+    "pn2_mlp_chain_bwd_f32": (_int, [_vp, _i64, _int, _lp, _int, _int, _vp, _vp, _vp, _i64, _int, _vp, _vp, _sp, _int, _tp, _cp, _vp,
+                                     _sz, _vp]),
     "pn2_cylinder_project_f32": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _vp]),
     "pn2_raster_ranges_f32": (_int, [_vp, _i64, _int, _vp, _int, _int, _int, _vp, _vp, _vp]),
     "pn2_raster_keys": (_int, [_vp, _vp, _int, _int, _int, _vp, _vp]),
@@ -135,7 +143,7 @@ ABI_VERSION = 4                      # PN2_ABI_VERSION of include/pn2_hip.h
 CHAIN_ACCUMULATE_DX = 0x100          # PN2_CHAIN_ACCUMULATE_DX
 CHAIN_LAZY_OUT = 0x400               # PN2_CHAIN_LAZY_OUT
 CHAIN_ZERO_LEAD = 0x800              # PN2_CHAIN_ZERO_LEAD
-STATUS_FPS_HANDOFF, STATUS_FPS_ARRIVAL, STATUS_BAD_INDEX = 1, 2, 4   # PN2_STATUS_* bits
+STATUS_FPS_HANDOFF, STATUS_FPS_ARRIVAL, STATUS_BAD_INDEX, STATUS_COOP_BARRIER = 1, 2, 4, 8   # PN2_STATUS_* bits
 
 
 def lib():

@@ -20,469 +20,10 @@
 //                                     dgrad    dX = dY W            (A rows x Cout, B = W as [K][N])
 //                                     wgrad    dW = dY^T X          (reduction over rows, split over blocks,
 //                                                                    fixed-order slab sum -> deterministic)
-#include <stdlib.h>
-
-#include "pn2_common.h"
-#include <cstdlib>
+#include "chain_coop.h"
+#include "mlp_tile.h"
 
 namespace {
-
-constexpr int BK = 16, NT = 256;
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
-
-enum { TR_PLAIN = 0, TR_BNRELU = 1, TR_DY = 2 };
-enum { EPI_FWD = 0, EPI_STORE = 1, EPI_SLAB = 2 };
-// rows of a layer's coefficient block (each `C` floats): see pn2_mlp_layer.stats in pn2_hip.h
-enum { ST_MEAN = 0, ST_VAR = 1, ST_INVSTD = 2, ST_SCALE = 3, ST_BETA = 4, ST_A = 5, ST_B = 6, ST_ROWS = 8 };
-
-// Row SEGMENTS (whole-tree execution): the rows of a chain are the concatenation of nseg mini-batches, each with its
-// OWN train-mode BatchNorm statistics (the reference runs them as separate forward passes, PointNet2.py:238-306).
-// Every kernel that needs a row's statistics is launched over row BLOCKS that never straddle a segment boundary:
-// block i of a launch covers rows [row_off[s] + (i - blk_off[s]) * R, ...) of the segment s with
-// blk_off[s] <= i < blk_off[s+1] (R = the launch's block size: GEMM tile, reduction block, ...).  The table travels BY
-// VALUE in the kernel arguments (kernarg segment: scalar loads), so there is nothing to build or upload on the device.
-// nseg == 1 is the ordinary batch: block i covers rows [i * R, ...).
-constexpr int kMaxSegs = PN2_MAX_SEGMENTS;
-struct SegTable {
-    int nseg;
-    int row_off[kMaxSegs + 1];
-    int blk_off[kMaxSegs + 1];
-};
-struct RowBlock {
-    int seg, row0, row_end;
-};
-// wave-uniform: blockIdx -> (segment, first row, end of the segment)
-__device__ __forceinline__ RowBlock row_block(const SegTable& st, int blk, int R) {
-    int lo = 0, hi = st.nseg;
-    while (hi - lo > 1) {  // largest s with blk_off[s] <= blk
-        const int mid = (lo + hi) >> 1;
-        if (st.blk_off[mid] <= blk) lo = mid; else hi = mid;
-    }
-    return RowBlock{lo, st.row_off[lo] + (blk - st.blk_off[lo]) * R, st.row_off[lo + 1]};
-}
-__device__ __forceinline__ int seg_of_row(const SegTable& st, int row) {
-    int lo = 0, hi = st.nseg;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (st.row_off[mid] <= row) lo = mid; else hi = mid;
-    }
-    return lo;
-}
-
-struct Operand {
-    const float* p;   // X, Y or dZ: [rows][cols], cols (= channels) contiguous
-    const float* q;   // TR_DY: the layer's pre-BN output Y
-    long long ld, ldq;
-    int rows, cols;
-    const float* coef;  // coefficient block [ST_ROWS][cstride] of the BatchNorm involved, or null
-    int cstride;
-    int relu;
-};
-
-// Branch-free tile loads: the address is clamped into the matrix and the value masked afterwards, so that all of
-// a thread's loads for a K-tile issue back to back and are waited for once (a branch per load made the compiler
-// wait for each load separately: 8-12 dependent memory round trips per K-tile).
-template <bool VEC>
-__device__ __forceinline__ float4 ld4(const float* base, long long ld, int r, int c, int nrows, int ncols) {
-    const int rc = r < nrows ? r : nrows - 1;
-    if (VEC) {  // ncols % 4 == 0 and c % 4 == 0: c < ncols implies c + 3 < ncols
-        const int cc = c < ncols ? c : ncols - 4;
-        return *(const float4*)(base + (long long)rc * ld + cc);
-    }
-    const float* p = base + (long long)rc * ld;
-    const int last = ncols - 1;
-    float4 v;
-    v.x = p[c < last ? c : last];
-    v.y = p[c + 1 < last ? c + 1 : last];
-    v.z = p[c + 2 < last ? c + 2 : last];
-    v.w = p[c + 3 < last ? c + 3 : last];
-    return v;
-}
-
-// One operand's staging state for a TILE x 32 (T layout: global [outer][k]) or 32 x TILE (D layout: global
-// [k][outer]) tile: TILE/32 float4 per thread (+ as many for the second source) and the BatchNorm coefficients
-// of the thread's 4 channels in registers.  The channel is always the contiguous global index: k for the T
-// layout (reloaded per K-tile), the outer index for the D layout (loaded once).
-template <bool T_LAYOUT, int KIND, int TILE, bool VEC, int THREADS = NT>
-struct Stager {
-    static constexpr int NP = TILE * BK / (4 * THREADS);   // 16-byte loads per thread per K-tile
-    static constexpr int KT = BK / 4;        // T layout: threads along k per row
-    static constexpr int RPP = THREADS / KT; // T layout: rows per pass
-    static constexpr int OQ = TILE / 4;      // D layout: threads per k-row
-    static constexpr int KPP = THREADS / OQ; // D layout: k-rows per pass
-    static constexpr int LD = TILE + 4;
-    float4 v[NP], y[NP];
-    float cm[4], cs[4], cb[4], ca[4], cq[4];
-    int tid;  // thread index inside the 256-thread team that stages this tile
-
-    __device__ __forceinline__ int chan0(int o0, int k0) const {
-        return T_LAYOUT ? k0 + 4 * (tid % KT) : o0 + 4 * (tid % OQ);
-    }
-    __device__ __forceinline__ int row_of(int p, int o0, int k0) const {
-        return T_LAYOUT ? o0 + RPP * p + (tid / KT) : k0 + KPP * p + (tid / OQ);
-    }
-    __device__ __forceinline__ void load_coefs(const Operand& o, int c0) {
-        if (KIND == TR_PLAIN) return;
-        if (VEC) {  // cols % 4 == 0: one 16-byte load per coefficient row (the block is [8][cols], 16-byte aligned)
-            const int cc = c0 < o.cols ? c0 : o.cols - 4;
-            const float4 m4 = *(const float4*)(o.coef + ST_MEAN * o.cstride + cc);
-            const float4 s4 = *(const float4*)(o.coef + ST_SCALE * o.cstride + cc);
-            const float4 b4 = *(const float4*)(o.coef + ST_BETA * o.cstride + cc);
-            cm[0] = m4.x; cm[1] = m4.y; cm[2] = m4.z; cm[3] = m4.w;
-            cs[0] = s4.x; cs[1] = s4.y; cs[2] = s4.z; cs[3] = s4.w;
-            cb[0] = b4.x; cb[1] = b4.y; cb[2] = b4.z; cb[3] = b4.w;
-            if (KIND == TR_DY) {
-                const float4 a4 = *(const float4*)(o.coef + ST_A * o.cstride + cc);
-                const float4 q4 = *(const float4*)(o.coef + ST_B * o.cstride + cc);
-                ca[0] = a4.x; ca[1] = a4.y; ca[2] = a4.z; ca[3] = a4.w;
-                cq[0] = q4.x; cq[1] = q4.y; cq[2] = q4.z; cq[3] = q4.w;
-            }
-            return;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int ch = c0 + j < o.cols ? c0 + j : o.cols - 1;
-            cm[j] = o.coef[ST_MEAN * o.cstride + ch];
-            cs[j] = o.coef[ST_SCALE * o.cstride + ch];
-            cb[j] = o.coef[ST_BETA * o.cstride + ch];
-            if (KIND == TR_DY) {
-                ca[j] = o.coef[ST_A * o.cstride + ch];
-                cq[j] = o.coef[ST_B * o.cstride + ch];
-            }
-        }
-    }
-    __device__ __forceinline__ void prepare(const Operand& o, int o0) {
-        if (!T_LAYOUT) load_coefs(o, chan0(o0, 0));
-    }
-    __device__ __forceinline__ void fetch(const Operand& o, int o0, int k0) {
-        const int c = chan0(o0, k0);
-        if (T_LAYOUT) load_coefs(o, c);
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            const int r = row_of(p, o0, k0);
-            v[p] = ld4<VEC>(o.p, o.ld, r, c, o.rows, o.cols);
-            if (KIND == TR_DY) y[p] = ld4<VEC>(o.q, o.ldq, r, c, o.rows, o.cols);
-        }
-    }
-    __device__ __forceinline__ float xf(float val, float yy, int j, int relu) const {
-        if (KIND == TR_PLAIN) return val;
-        if (KIND == TR_BNRELU) {
-            const float t = __builtin_fmaf(val - cm[j], cs[j], cb[j]);
-            return relu ? fmaxf(t, 0.0f) : t;
-        }
-        const float t = __builtin_fmaf(yy - cm[j], cs[j], cb[j]);
-        const float dz = (!relu || t > 0.0f) ? val : 0.0f;
-        return cs[j] * (dz - ca[j] - (yy - cm[j]) * cq[j]);
-    }
-    // stage pass p of the fetched tile into the LDS image (transform applied here, once per element)
-    __device__ __forceinline__ void commit_pass(const Operand& o, float* S, int o0, int k0, int p) {
-        const int c = chan0(o0, k0);
-        const int r = row_of(p, o0, k0);
-        const float e[4] = {v[p].x, v[p].y, v[p].z, v[p].w};
-        const float yy[4] = {y[p].x, y[p].y, y[p].z, y[p].w};
-        float w[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            // elements outside the matrix must be exactly zero: they pad the contraction
-            const bool in = r < o.rows && c + j < o.cols;
-            w[j] = in ? xf(e[j], KIND == TR_DY ? yy[j] : 0.0f, j, o.relu) : 0.0f;
-        }
-        if (T_LAYOUT) {
-            const int m = RPP * p + (tid / KT), k = 4 * (tid % KT);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) S[(k + j) * LD + m] = w[j];
-        } else {
-            const int k = KPP * p + (tid / OQ), m = 4 * (tid % OQ);
-            *(float4*)(S + k * LD + m) = make_float4(w[0], w[1], w[2], w[3]);
-        }
-    }
-    __device__ __forceinline__ void commit(const Operand& o, float* S, int o0, int k0) {
-#pragma unroll
-        for (int p = 0; p < NP; ++p) commit_pass(o, S, o0, k0, p);
-    }
-};
-
-struct GemmArgs {
-    Operand A, B;
-    int M, N, K;          // C[M][N] = sum_k A[m][k] B[k][n]
-    float* C;             // EPI_FWD: Y [M][ldc]; EPI_STORE: [M][ldc]; EPI_SLAB: [split][M][ldc]
-    long long ldc;
-    const float* bias;    // EPI_FWD, may be null
-    float* partial;       // EPI_FWD: [ceil(M/64)][2][N] (mean, M2) per 64-row chunk; EPI_STORE: (s1, s2); or null
-    int k_per_split;      // EPI_SLAB: K range per blockIdx.z
-    // EPI_STORE with partial: the output is dZ of the PREVIOUS layer; its BatchNorm-backward column sums are taken
-    // here from the accumulators (needs that layer's Y and coefficient block)
-    const float* ey;
-    long long ldey;
-    const float* ecoef;
-    int erelu;
-    long long pstride;    // partial layout: 0 = [chunk][2][N] (row-major); else channel-major, column c at c * pstride + 2 * chunk
-    int precision;        // host side only: PN2_PRECISION_* of the 128-tile contraction (travels with the call, no global state)
-    int accumulate;       // EPI_STORE: C += result (PN2_CHAIN_ACCUMULATE_DX): the accumulators START from C -- the loads
-                          // travel with the first K-tile's instead of forming a read-modify-write chain in the epilogue
-};
-
-// TILE = 128: four waves own 64 x 64 each (2 x 2 MFMA accumulators); TILE = 64: 32 x 32 each (one accumulator),
-// for problems too small to fill the chip with 128-tiles.
-// Epilogue shared by the GEMM kernels: the wave owns NI x NI 32x32 accumulators whose top-left element is
-// (row0, col0); chunk_rows = rows covered by one wave (= one statistics chunk).
-// FULL: the wave's sub-tile lies inside the matrix -- no per-element bounds checks (64 predicated stores otherwise)
-template <int EPI, int NI, bool FULL>
-__device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& g, f32x16 (&acc)[NI][NI], int row0, int col0, int chunk_rows,
-                                              int lane, int split, long long chunk) {
-    const int l31 = lane & 31, half = lane >> 5;
-    const int m0 = row0, wm = 0, WT = chunk_rows, n0 = col0, wn = 0;   // names used by the body below
-    // statistics partials: element (chunk, which, col) at chunk * pchunk + which * pwhich + col * pcol --
-    // row-major [chunk][2][N] or channel-major (GemmArgs::pstride)
-    const long long pchunk = g.pstride ? 2 : 2ll * g.N, pcol = g.pstride ? g.pstride : 1, pwhich = g.pstride ? 1 : g.N;
-    (void)wm; (void)wn;
-    // ---- epilogue.  C/D layout of 32x32x2: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
-    float* C = g.C;
-    if (EPI == EPI_SLAB) C += (long long)split * g.M * g.ldc;
-    const int rbase = m0 + wm * WT + 4 * half;
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        const int col = n0 + wn * WT + 32 * j + l31;
-        const bool cok = FULL || col < g.N;
-        const float bias = (EPI == EPI_FWD && g.bias && cok) ? g.bias[col] : 0.0f;
-        float sum = 0.0f;
-        int cnt = 0;
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rbase + 32 * i + (r & 3) + 8 * (r >> 2);
-                const float val = acc[i][j][r] + bias;
-                acc[i][j][r] = val;
-                if (FULL || row < g.M) {
-                    if (cok) C[(long long)row * g.ldc + col] = val;
-                    sum += val;
-                    ++cnt;
-                }
-            }
-        // per-(row chunk of WT rows, column) partials; the other half-wave holds the other rows of the column
-        if (EPI == EPI_FWD && g.partial) {
-            sum += __shfl_xor(sum, 32, 64);
-            cnt += __shfl_xor(cnt, 32, 64);
-            const float mean = cnt > 0 ? sum / (float)cnt : 0.0f;
-            float m2 = 0.0f;
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rbase + 32 * i + (r & 3) + 8 * (r >> 2);
-                    const float d = acc[i][j][r] - mean;
-                    if (FULL || row < g.M) m2 += d * d;
-                }
-            m2 += __shfl_xor(m2, 32, 64);
-            if (half == 0 && cok && m0 + wm * WT < g.M) {
-                // one address formula for both layouts (a branch here costs the dgrad kernel 50 us: measured)
-                float* pp = g.partial + chunk * pchunk + (long long)col * pcol;
-                pp[0] = mean;
-                pp[pwhich] = m2;
-            }
-        }
-        if (EPI == EPI_STORE && g.partial) {
-            // BatchNorm-backward sums of the layer whose dZ this tile is: s1 = sum mask*dz, s2 = sum mask*dz*xhat
-            const int cc = cok ? col : 0;
-            const float mean = g.ecoef[ST_MEAN * g.N + cc], sc = g.ecoef[ST_SCALE * g.N + cc];
-            const float bt = g.ecoef[ST_BETA * g.N + cc], invstd = g.ecoef[ST_INVSTD * g.N + cc];
-            float s1 = 0.0f, s2 = 0.0f;
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rbase + 32 * i + (r & 3) + 8 * (r >> 2);
-                    const int rr = (FULL || row < g.M) ? row : g.M - 1;
-                    const float yy = g.ey[(long long)rr * g.ldey + cc];
-                    const float t = __builtin_fmaf(yy - mean, sc, bt);
-                    const float dzh = ((FULL || row < g.M) && (!g.erelu || t > 0.0f)) ? acc[i][j][r] : 0.0f;
-                    s1 += dzh;
-                    s2 += dzh * ((yy - mean) * invstd);
-                }
-            s1 += __shfl_xor(s1, 32, 64);
-            s2 += __shfl_xor(s2, 32, 64);
-            if (half == 0 && cok && m0 + wm * WT < g.M) {
-                float* pp = g.partial + chunk * pchunk + (long long)col * pcol;
-                pp[0] = s1;
-                pp[pwhich] = s2;
-            }
-        }
-    }
-}
-
-template <int EPI, int NI>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[NI][NI], int row0, int col0, int chunk_rows,
-                                              int lane, int split, long long chunk) {
-    if (row0 + 32 * NI <= g.M && col0 + 32 * NI <= g.N)
-        gemm_epilogue_impl<EPI, NI, true>(g, acc, row0, col0, chunk_rows, lane, split, chunk);
-    else
-        gemm_epilogue_impl<EPI, NI, false>(g, acc, row0, col0, chunk_rows, lane, split, chunk);
-}
-
-// TEAMS = 4 (64-tiles only): the block holds four 256-thread teams that each contract a quarter of K into their own
-// accumulators and LDS buffers; the quarters are summed through LDS at the end.  Deep levels have GEMMs with a few
-// hundred rows and K up to 768: a handful of workgroups whose serial K loop is pure latency -- four teams put four
-// times the loads in flight and give every SIMD four waves to interleave.
-// BF16 (throughput mode, 128-tiles only): the operands are rounded to bfloat16 (round to nearest even) on their way from
-// the fp32 LDS image into the matrix core and multiplied by v_mfma_f32_32x32x16_bf16 -- one instruction per K-tile and
-// accumulator instead of eight fp32 ones, fp32 accumulation, everything else (staging, transforms, epilogues, what is
-// stored in HBM) unchanged.  The contraction then costs 1/8 of the matrix-pipe time and the kernel is bound by HBM.
-// ACC (EPI_STORE only): the accumulators start from C (GemmArgs::accumulate) -- a variant of its own: even a never-taken
-// branch around those 64 loads costs every other dgrad launch ~10 us.
-template <bool A_T, int A_KIND, bool B_T, int B_KIND, int EPI, int TILE, bool VEC, int TEAMS, bool BF16 = false, bool ACC = false>
-__global__ __launch_bounds__(NT * TEAMS, (TEAMS > 1 ? 1 : (EPI == EPI_STORE ? 2 : 3))) void gemm_kernel(const GemmArgs g0,
-                                                                                                         const SegTable st) {
-    constexpr int LD = TILE + 4, WT = TILE / 2, NI = WT / 32;
-    // Which rows does this workgroup own?  Row tiles (forward, dgrad) and reduction ranges (wgrad) never straddle a
-    // segment: the operands' row limit, the output's row limit and the BatchNorm coefficient blocks are those of the
-    // block's segment (st.nseg == 1: the whole matrix, coefficient block 0).
-    GemmArgs g = g0;
-    int m0 = blockIdx.x * TILE, k_begin = 0, k_end = g.K, seg;
-    if (EPI == EPI_SLAB) {
-        const RowBlock rb = row_block(st, (int)blockIdx.z, g.k_per_split);
-        seg = rb.seg;
-        k_begin = rb.row0;
-        k_end = rb.row0 + g.k_per_split < rb.row_end ? rb.row0 + g.k_per_split : rb.row_end;
-        g.A.rows = g.B.rows = k_end;        // direct layout: rows are the contraction index
-    } else {
-        const RowBlock rb = row_block(st, (int)blockIdx.x, TILE);
-        seg = rb.seg;
-        m0 = rb.row0;
-        g.A.rows = g.M = rb.row_end;
-    }
-    if (g.A.coef) g.A.coef += (long long)seg * ST_ROWS * g.A.cstride;
-    if (g.B.coef) g.B.coef += (long long)seg * ST_ROWS * g.B.cstride;
-    if (EPI == EPI_STORE && g.ecoef) g.ecoef += (long long)seg * ST_ROWS * g.N;
-    static_assert(TEAMS == 1 || TILE == 64, "teams are for the small-problem tile");
-    // one LDS object (it is re-used as the teams' reduction buffer): [team][A|B][buffer][BK * LD]
-    __shared__ __attribute__((aligned(16))) float lds[TEAMS * 4 * BK * LD];
-    const int team = (int)threadIdx.x / NT, tid = (int)threadIdx.x % NT;
-    float(*As)[BK * LD] = (float(*)[BK * LD])(lds + (team * 4 + 0) * BK * LD);
-    float(*Bs)[BK * LD] = (float(*)[BK * LD])(lds + (team * 4 + 2) * BK * LD);
-
-    const int n0 = blockIdx.y * TILE;
-    int nk = (k_end - k_begin + BK - 1) / BK;
-    if (TEAMS > 1) {  // every team runs the same number of K-tiles (loads beyond K are zero-filled)
-        nk = (nk + TEAMS - 1) / TEAMS;
-        k_begin += team * nk * BK;
-    }
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, half = lane >> 5;
-
-    f32x16 acc[NI][NI];
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    if (ACC && EPI == EPI_STORE && team == 0) {   // uniform per wavefront; the other teams add their partial tiles later
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                const int col = n0 + wn * WT + 32 * j + l31;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wm * WT + 4 * half + 32 * i + (r & 3) + 8 * (r >> 2);
-                    if (row < g.M && col < g.N) acc[i][j][r] = g.C[(long long)row * g.ldc + col];
-                }
-            }
-    }
-
-    Stager<A_T, A_KIND, TILE, VEC> sa;
-    Stager<B_T, B_KIND, TILE, VEC> sb;
-    sa.tid = tid;
-    sb.tid = tid;
-    sa.prepare(g.A, m0);
-    sb.prepare(g.B, n0);
-    if (nk > 0) {
-        sa.fetch(g.A, m0, k_begin);
-        sb.fetch(g.B, n0, k_begin);
-        sa.commit(g.A, As[0], m0, k_begin);
-        sb.commit(g.B, Bs[0], n0, k_begin);
-    }
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        const int knext = k_begin + (kt + 1) * BK;
-        if (kt + 1 < nk) {
-            sa.fetch(g.A, m0, knext);
-            sb.fetch(g.B, n0, knext);
-        }
-        const float* a = As[cur] + wm * WT + l31;
-        const float* b = Bs[cur] + wn * WT + l31;
-        // The K-tile's MFMAs are issued in NP groups; after each group one pass of the NEXT tile is staged into the
-        // other LDS buffer, so the staging VALU/LDS work sits in the shadow of the (asynchronous, 64-cycle) MFMAs
-        // instead of forming a separate phase during which this wave's matrix pipe idles.
-        constexpr int NP = TILE * BK / (4 * NT), KQ = BK / NP;
-        if constexpr (BF16) {
-            static_assert(!BF16 || BK == 16, "one 32x32x16 MFMA consumes a whole K-tile");
-            // lane (r = lane & 31, h = lane >> 5) supplies A[row r][k = 8h + e] and B[k = 8h + e][col r], e = 0..7
-            bf16x8 af[NI], bf[NI];
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    af[i][e] = (__bf16)a[(8 * half + e) * LD + 32 * i];
-                    bf[i][e] = (__bf16)b[(8 * half + e) * LD + 32 * i];
-                }
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-#pragma unroll
-                for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-            if (kt + 1 < nk) {
-                sa.commit(g.A, As[cur ^ 1], m0, knext);
-                sb.commit(g.B, Bs[cur ^ 1], n0, knext);
-            }
-        } else
-#pragma unroll
-        for (int q = 0; q < NP; ++q) {
-#pragma unroll
-            for (int kk = q * KQ; kk < (q + 1) * KQ; kk += 2) {
-                const int ko = (kk + half) * LD;
-                float av[NI], bv[NI];
-#pragma unroll
-                for (int i = 0; i < NI; ++i) {
-                    av[i] = a[ko + 32 * i];
-                    bv[i] = b[ko + 32 * i];
-                }
-#pragma unroll
-                for (int i = 0; i < NI; ++i)
-#pragma unroll
-                    for (int j = 0; j < NI; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-            }
-            if (kt + 1 < nk) {
-                sa.commit_pass(g.A, As[cur ^ 1], m0, knext, q);
-                sb.commit_pass(g.B, Bs[cur ^ 1], n0, knext, q);
-            }
-        }
-        __syncthreads();
-    }
-
-    if (TEAMS > 1) {
-        // sum the teams' partial tiles through LDS (the staging buffers are free now); team 0 runs the epilogue
-        float* red = lds;   // (TEAMS - 1) x NT x 16 floats = 48 KiB of the 68 KiB
-        static_assert(TEAMS == 1 || (TEAMS - 1) * 16 * NT <= TEAMS * 4 * BK * LD, "reduction buffer must fit");
-        if (team > 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) red[((team - 1) * 16 + r) * NT + tid] = acc[0][0][r];
-        }
-        __syncthreads();
-        if (team > 0) return;
-#pragma unroll
-        for (int t = 0; t < TEAMS - 1; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[0][0][r] += red[(t * 16 + r) * NT + tid];
-    }
-
-    gemm_epilogue<EPI, NI>(g, acc, m0 + wm * WT, n0 + wn * WT, WT, lane, (int)blockIdx.z,
-                           (long long)blockIdx.x * (TILE / WT) + wm);
-}
 
 // (chunk, which) element of one channel's statistics partials in either layout (GemmArgs::pstride)
 struct PartialView {
@@ -1491,38 +1032,6 @@ inline void flush_slab_tasks(SlabTasks& T, hipStream_t s) {
     T.n = T.blocks = 0;
 }
 
-inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
-
-// vector (16 B) staging is legal when rows start 16-byte aligned and the contiguous extent is a multiple of 4
-inline int vec_ok(const Operand& o) {
-    return (o.ld % 4 == 0) && (o.cols % 4 == 0) && aligned16(o.p) && (!o.q || (o.ldq % 4 == 0 && aligned16(o.q)));
-}
-
-Operand plain(const float* p, long long ld, int rows, int cols) {
-    Operand o{};
-    o.p = p;
-    o.ld = ld;
-    o.rows = rows;
-    o.cols = cols;
-    return o;
-}
-
-// activation source of a layer: raw rows (first layer) or the previous layer's Y seen through its BN+ReLU
-struct Act {
-    const float* p;
-    long long ld;
-    const float* coef;  // null -> plain
-    int relu;
-};
-
-Operand act_operand(const Act& a, int rows, int cols) {
-    Operand o = plain(a.p, a.ld, rows, cols);
-    o.coef = a.coef;
-    o.cstride = cols;
-    o.relu = a.relu;
-    return o;
-}
-
 // Tile choice: 128-tiles unless they would leave most of the chip idle (deep levels have a few hundred rows).
 inline int pick_tile(int M, int N, int nsplit) {
     // (128-row tiles for narrow outputs of long matrices were measured: 20.8 -> 21.3 .. 22.5 ms per raster-mode tree)
@@ -1750,10 +1259,20 @@ inline long long cm_stride(int rows, int tile, int nseg) {
 // row-block size of the dgrad that produces a linked chain's input gradient (two partial chunks per block)
 inline int link_tile(int rows, int cin) { return pick_tile(rows, cin, 1); }
 
+// cooperative launches: asked for by the caller (a sync buffer) and not switched off (PN2_NO_COOP: A/B and test aid)
+inline bool coop_usable(const pn2_coop* c) {
+    return c && c->sync && !getenv("PN2_NO_COOP");
+}
+
+// bytes of ONE of the two partial regions at the start of a chain workspace (behind the segmented finalizes' scratch)
+namespace {
+size_t partial_region_bytes(int rows, const pn2_mlp_layer* layers, int nlayers, int nseg);
+}
+
 // ===================================================================================================== C ABI
-extern "C" size_t pn2_mlp_workspace_bytes(int rows, const pn2_mlp_layer* layers, int nlayers, int nseg) {
-    if (rows <= 0 || !layers || nlayers <= 0) return 0;
-    if (nseg < 1) nseg = 1;
+namespace {
+// (shared scratch need of the layers, slab arena) of a chain workspace
+void workspace_parts(int rows, const pn2_mlp_layer* layers, int nlayers, int nseg, size_t* need_out, size_t* arena_out) {
     size_t need = 0, arena = 0;
     for (int i = 0; i < nlayers; ++i) {
         const size_t cin = layers[i].cin, cout = layers[i].cout;
@@ -1771,7 +1290,23 @@ extern "C" size_t pn2_mlp_workspace_bytes(int rows, const pn2_mlp_layer* layers,
         need = need > m ? need : m;
         arena += align256(slab);   // the weight-gradient slabs of ALL layers stay until the chain's one reduction launch
     }
-    return slice_region_of(rows, layers, nlayers, nseg) + align256(need) + 256 + arena;
+    *need_out = align256(need);
+    *arena_out = arena;
+}
+size_t partial_region_bytes(int rows, const pn2_mlp_layer* layers, int nlayers, int nseg) {
+    size_t need = 0, arena = 0;
+    workspace_parts(rows, layers, nlayers, nseg, &need, &arena);
+    return need;
+}
+}  // namespace
+
+extern "C" size_t pn2_mlp_workspace_bytes(int rows, const pn2_mlp_layer* layers, int nlayers, int nseg) {
+    if (rows <= 0 || !layers || nlayers <= 0) return 0;
+    if (nseg < 1) nseg = 1;
+    size_t need = 0, arena = 0;
+    workspace_parts(rows, layers, nlayers, nseg, &need, &arena);
+    // (two partial regions: the cooperative chain kernels alternate between them from layer to layer)
+    return slice_region_of(rows, layers, nlayers, nseg) + 2 * need + 256 + arena;
 }
 
 namespace {
@@ -1788,7 +1323,7 @@ size_t slab_arena_offset(int rows, const pn2_mlp_layer* layers, int nlayers, int
 
 extern "C" int pn2_mlp_chain_fwd_f32(const float* x, int64_t ldx, int rows, const pn2_mlp_layer* layers, int nlayers,
                                      int training, int pool_k, float* out, int32_t* pool_arg, const pn2_segments* segments,
-                                     int precision, void* workspace, size_t workspace_bytes, void* stream) {
+                                     int precision, const pn2_coop* coop, void* workspace, size_t workspace_bytes, void* stream) {
     const bool lazy_out = (precision & PN2_CHAIN_LAZY_OUT) != 0;
     precision &= ~PN2_CHAIN_LAZY_OUT;
     if (!x || !layers || nlayers <= 0 || rows <= 0 || (!out && !lazy_out) || (pool_k > 1 && (!pool_arg || rows % pool_k)))
@@ -1801,6 +1336,16 @@ extern "C" int pn2_mlp_chain_fwd_f32(const float* x, int64_t ldx, int rows, cons
     hipStream_t s = (hipStream_t)stream;
     const FinScratch sp = fin_scratch(workspace, S.nseg, chain_cmax(layers, nlayers));   // segmented finalizes' scratch
     workspace = (char*)workspace + slice_region_of(rows, layers, nlayers, S.nseg);
+    if (coop_usable(coop) && training && S.nseg == 1 && !lazy_out && !layers[0].in_stats && out &&
+        pn2::coop::shapes_ok(rows, layers, nlayers, pool_k)) {
+        // a deep level: the whole chain as one persistent launch (chain_coop.hip)
+        pn2::coop::FwdCall c{};
+        c.x = x, c.ldx = ldx, c.rows = rows, c.layers = layers, c.nlayers = nlayers, c.pool_k = pool_k, c.out = out, c.arg = pool_arg;
+        c.partial[0] = (float*)workspace;
+        c.partial[1] = (float*)((char*)workspace + partial_region_bytes(rows, layers, nlayers, S.nseg));
+        c.ctl = coop, c.stream = s;
+        return pn2::coop::forward(c);
+    }
     Act in{x, ldx, layers[0].in_stats, layers[0].in_stats ? layers[0].in_relu : 0};   // linked chain: BN(+ReLU) while staging
     for (int i = 0; i < nlayers; ++i) {
         const pn2_mlp_layer& L = layers[i];
@@ -1871,8 +1416,8 @@ extern "C" int pn2_mlp_chain_fwd_f32(const float* x, int64_t ldx, int rows, cons
 extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, const pn2_mlp_layer* layers, int nlayers,
                                      int pool_k, const float* dout, const int32_t* pool_arg, float* dx, int64_t lddx,
                                      int dx_first_col, float* scratch_a, float* scratch_b, const pn2_segments* segments,
-                                     int precision, pn2_wgrad_tasks* deferred, void* workspace, size_t workspace_bytes,
-                                     void* stream) {
+                                     int precision, pn2_wgrad_tasks* deferred, const pn2_coop* coop, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
     if (!x || !layers || nlayers <= 0 || rows <= 0 || !dout || !scratch_a || !scratch_b) return PN2_E_BADARG;
     if (dx_first_col < 0 || dx_first_col >= layers[0].cin) return PN2_E_BADARG;
     const int accumulate_dx = (precision & PN2_CHAIN_ACCUMULATE_DX) ? 1 : 0;
@@ -1891,6 +1436,50 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
     float* ws = (float*)((char*)workspace + slice_region_of(rows, layers, nlayers, S.nseg));
     char* arena = (char*)workspace + slab_arena_offset(rows, layers, nlayers, S.nseg);
     SlabTasks tasks{};
+    if (coop_usable(coop) && S.nseg == 1 && !accumulate_dx && !layers[0].in_stats && !layers[0].in_partial &&
+        !layers[nlayers - 1].out_partial && (pool_k <= 1 || pool_arg) && (dx_first_col == 0 || zero_lead || !dx) &&
+        pn2::coop::shapes_ok(rows, layers, nlayers, pool_k)) {
+        // a deep level: the whole backward chain as one persistent launch (chain_coop.hip); the slab reductions stay with
+        // the caller exactly as on the launch-per-layer path
+        pn2::coop::BwdCall c{};
+        c.x = x, c.ldx = ldx, c.rows = rows, c.layers = layers, c.nlayers = nlayers, c.pool_k = pool_k, c.dout = dout, c.arg = pool_arg;
+        c.dx = dx, c.lddx = lddx, c.dx_first_col = dx_first_col, c.zero_lead = zero_lead ? 1 : 0;
+        c.scratch[0] = scratch_a, c.scratch[1] = scratch_b;
+        c.partial[0] = ws;
+        c.partial[1] = (float*)((char*)ws + partial_region_bytes(rows, layers, nlayers, S.nseg));
+        c.ctl = coop, c.stream = s;
+        for (int i = nlayers - 1; i >= 0; --i) {
+            const pn2_mlp_layer& L = layers[i];
+            if (!L.dweight) continue;
+            const WgradPlan wp = plan_wgrad(rows, L.cout, L.cin, S.nseg);      // sizes the arena (pn2_mlp_workspace_bytes)
+            int kps = 0, nsplit = 0;
+            pn2::coop::plan_slabs(rows, L.cout, L.cin, &kps, &nsplit);
+            if (nsplit > wp.nsplit) {
+                kps = pn2::ceil_div(pn2::ceil_div(rows, wp.nsplit), 4 * BK) * 4 * BK;
+                nsplit = pn2::ceil_div(rows, kps);
+            }
+            c.slab[i] = (float*)arena, c.kps[i] = kps, c.nsplit[i] = nsplit;
+            if (!defer_wgrad) {
+                bool clash = tasks.n == SLAB_TASKS;
+                for (int t = 0; t < tasks.n && !clash; ++t) clash = tasks.t[t].out == L.dweight;
+                if (clash) return PN2_E_BADARG;   // (a weight shared by two layers of one chain: not cooperative)
+            }
+            add_slab_task(tasks, (const float*)arena, nsplit, (long long)L.cout * L.cin, L.dweight);
+            arena += align256((size_t)wp.nsplit * L.cout * L.cin * sizeof(float));
+        }
+        const int st = pn2::coop::backward(c);
+        if (st) return st;
+        if (defer_wgrad) {
+            for (int i = 0; i < tasks.n; ++i) {
+                pn2_wgrad_task& t = deferred->t[deferred->n++];
+                t.slab = tasks.t[i].slab, t.out = tasks.t[i].out, t.mn = tasks.t[i].mn, t.nsplit = tasks.t[i].nsplit, t.reserved = 0;
+            }
+        } else {
+            flush_slab_tasks(tasks, s);
+        }
+        PN2_LAUNCH_CHECK();
+        return 0;
+    }
     // dz of the last layer: upstream gradient, or the max-pool scatter of it
     const float* dz = dout;
     long long lddz = layers[nlayers - 1].cout;

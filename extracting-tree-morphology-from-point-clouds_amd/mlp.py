@@ -43,6 +43,13 @@ GEMM_PRECISION = "f32"
 _PRECISION_CODE = {"f32": 0, "bf16": 1}
 
 
+def _coop(dev):
+    """The deep levels' chains run as one persistent launch per direction when the caller hands over arrival counters
+    (include/pn2_hip.h: pn2_coop); the library decides per call (PN2_NO_COOP=1 switches it off there)."""
+    from . import ops
+    return ops.coop_ctl(dev)
+
+
 def _grad_target(leaf, value, need, dev):
     """-> (tensor the kernels accumulate into or None, gradient to return to autograd or None)."""
     if value is None or not need:
@@ -116,7 +123,7 @@ class _ChainFn(torch.autograd.Function):
         nbytes = 4 * rows * (cin0 + 2 * sum(int(a.cout) for a in arr))
         _hip.call("mlp_chain_fwd", lib.pn2_mlp_chain_fwd_f32, x.data_ptr(), x.stride(0), rows, arr, n, int(training),
                   int(pool_k), _hip.ptr(out), _hip.ptr(arg), seg_ptr, precision | (_hip.CHAIN_LAZY_OUT if lazy_out else 0),
-                  ws.data_ptr(), ws.numel(), _hip.stream_ptr(), nbytes=nbytes, flops=flops)
+                  _coop(dev), ws.data_ptr(), ws.numel(), _hip.stream_ptr(), nbytes=nbytes, flops=flops)
         ctx.meta = meta
         ctx.nseg = nseg
         ctx.precision = precision
@@ -216,7 +223,7 @@ class _ChainFn(torch.autograd.Function):
             arr[0].in_partial = None
         _hip.call("mlp_chain_bwd", lib.pn2_mlp_chain_bwd_f32, x.data_ptr(), x.stride(0), rows, arr, n, int(meta["pool_k"]),
                   dout.data_ptr(), _hip.ptr(arg), _hip.ptr(dx), cin0, skip, sa.data_ptr(), sb.data_ptr(), seg_ptr, flags,
-                  deferred, ws.data_ptr(), ws.numel(), _hip.stream_ptr(), nbytes=nbytes, flops=flops)
+                  deferred, _coop(dev), ws.data_ptr(), ws.numel(), _hip.stream_ptr(), nbytes=nbytes, flops=flops)
         if emit is not None:
             link.handle["partial"] = emit
         return (dx, None, *grads)

@@ -34,7 +34,9 @@ _status_words = {}
 _STATUS_TEXT = {_hip.STATUS_FPS_HANDOFF: "farthest_point_sample: a workgroup hand-off timed out (GPU shared with another "
                                          "kernel?); the unfinished rows hold -1 / NaN",
                 _hip.STATUS_FPS_ARRIVAL: "farthest_point_sample: the launch's workgroups were not co-resident",
-                _hip.STATUS_BAD_INDEX: "a gather was handed an index outside [0, N)"}
+                _hip.STATUS_BAD_INDEX: "a gather was handed an index outside [0, N)",
+                _hip.STATUS_COOP_BARRIER: "a cooperative MLP chain launch: a workgroup never reached a layer barrier (GPU shared "
+                                          "with another kernel?); the chain's results are garbage"}
 
 
 def status_word(device):
@@ -47,6 +49,26 @@ def status_word(device):
     return t
 
 
+# Arrival counters of the cooperative chain launches (include/pn2_hip.h: pn2_coop.sync): 64 zeroed uint32 per (device, stream),
+# allocated once; the kernels leave them zeroed when they finish.  One buffer per stream because launches of one stream are
+# ordered, launches of two streams are not.
+_coop_ctl = {}
+
+
+def coop_ctl(device):
+    """-> ctypes pointer to the pn2_coop of `device`'s current stream (kept alive here)."""
+    dev = torch.device(device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    rec = _coop_ctl.get(key)
+    if rec is None:
+        words = torch.zeros(64, dtype=torch.int32, device=dev)
+        c = _hip.Coop(words.data_ptr(), status_word(dev).data_ptr(), 0, 0)
+        rec = _coop_ctl[key] = (ctypes.pointer(c), c, words)
+    return rec[0]
+
+
 def check_status(device=None, clear=True):
     """Raise RuntimeError if any kernel since the last check reported a failure on `device` (default: every device
     used so far).  Synchronises the device."""
@@ -57,6 +79,10 @@ def check_status(device=None, clear=True):
         if v:
             if clear:
                 t.zero_()
+                if v & _hip.STATUS_COOP_BARRIER:      # a dead cooperative launch leaves its arrival counters behind
+                    for (di, _), rec in _coop_ctl.items():
+                        if di == t.device.index:
+                            rec[2].zero_()
             bad += [f"{t.device}: {text}" for bit, text in _STATUS_TEXT.items() if v & bit]
     if bad:
         raise RuntimeError("libpn2hip reported failed kernels -- " + "; ".join(bad))

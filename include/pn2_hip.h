@@ -39,6 +39,7 @@ extern "C" {
 #define PN2_STATUS_FPS_HANDOFF 1 /* farthest_point_sample: a workgroup of a cloud's group never delivered its candidate */
 #define PN2_STATUS_FPS_ARRIVAL 2 /* farthest_point_sample: the launch's workgroups were not co-resident (busy GPU) */
 #define PN2_STATUS_BAD_INDEX 4   /* a gather / scatter kernel was handed an index outside [0, N) and skipped it */
+#define PN2_STATUS_COOP_BARRIER 8 /* a cooperative MLP chain launch: a workgroup never reached a layer barrier (busy GPU) */
 
 /* ABI version of the loaded library (compare with PN2_ABI_VERSION). */
 int pn2_version(void);
@@ -360,14 +361,36 @@ typedef struct pn2_wgrad_tasks {
  * PN2_CHAIN_ACCUMULATE_DX. */
 #define PN2_CHAIN_ZERO_LEAD 0x800
 
+/* Cooperative chain launches (the deep levels).  A chain of a few hundred to a few thousand rows is ~25 launches of 5-25 us
+ * each way -- GEMM, BatchNorm finalize, GEMM, ... -- whose time is launch ramp and drain, not work.  With a non-NULL `coop`
+ * such a chain (train mode, one segment, every layer a BatchNorm layer, rows <= PN2_COOP_MAX_ROWS) runs as ONE persistent
+ * launch per direction: every workgroup walks the layers' 64 x 64 tile lists, layers are separated by a grid-wide arrival
+ * counter instead of a kernel boundary, tiles that cross workgroups are stored write-through and read past the (per-XCD,
+ * mutually incoherent) L2, and every workgroup derives the BatchNorm coefficients it needs from the tile epilogues'
+ * partials itself (no finalize launches).  Same arithmetic per element as the launch-per-layer path (same tile code).
+ *   sync    >= 64 device uint32 words, ZEROED ONCE by the caller and then left alone; one buffer per stream on which chains
+ *           run (launches on one stream are ordered; the kernels leave the words zeroed again when they finish)
+ *   status  the sticky PN2_STATUS_* word (PN2_STATUS_COOP_BARRIER: a barrier timed out after spin_limit polls -- the launch
+ *           drains, its results are garbage; the caller re-zeroes `sync` before the next launch)
+ * All workgroups of a launch must be co-resident (at most one per compute unit, max_workgroups <= 256; 0 = default).
+ * NULL: always the launch-per-layer path. */
+#define PN2_COOP_MAX_ROWS 16384
+typedef struct pn2_coop {
+    uint32_t *sync;
+    int32_t *status;
+    uint32_t spin_limit;     /* 0 = default (1 << 22 polls, seconds) */
+    int32_t max_workgroups;  /* 0 = default (256) */
+} pn2_coop;
+
 size_t pn2_mlp_workspace_bytes(int rows, const pn2_mlp_layer *layers, int nlayers, int nseg);
 int pn2_mlp_chain_fwd_f32(const float *x, int64_t ldx, int rows, const pn2_mlp_layer *layers, int nlayers,
                           int training, int pool_k, float *out, int32_t *pool_arg, const pn2_segments *segments,
-                          int precision, void *workspace, size_t workspace_bytes, void *stream);
+                          int precision, const pn2_coop *coop, void *workspace, size_t workspace_bytes, void *stream);
 int pn2_mlp_chain_bwd_f32(const float *x, int64_t ldx, int rows, const pn2_mlp_layer *layers, int nlayers,
                           int pool_k, const float *dout, const int32_t *pool_arg, float *dx, int64_t lddx,
                           int dx_first_col, float *scratch_a, float *scratch_b, const pn2_segments *segments,
-                          int precision, pn2_wgrad_tasks *deferred, void *workspace, size_t workspace_bytes, void *stream);
+                          int precision, pn2_wgrad_tasks *deferred, const pn2_coop *coop, void *workspace,
+                          size_t workspace_bytes, void *stream);
 size_t pn2_mlp_link_partial_bytes(int rows, int cin, int nseg, int32_t *block_rows, int32_t *chunks_per_block);
 int pn2_mlp_reduce_wgrad(const pn2_wgrad_task *tasks, int n, void *stream);
 
