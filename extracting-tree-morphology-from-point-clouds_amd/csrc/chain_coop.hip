@@ -36,50 +36,98 @@ constexpr int kMaxC = pn2::coop::kMaxC;
 constexpr int kChunk = TL / 2;                      // rows per statistics chunk (one wavefront's rows of a tile)
 
 struct Sync {
-    unsigned* w;        // [0] arrivals, [1] departures, [2] dead flag
+    unsigned* w;        // [0] departures, [1] dead flag, phase p: [4 + 2 p] tickets handed out, [5 + 2 p] items done
     int* status;
     unsigned spin_limit;
 };
 
-// Grid barrier.  Every store of the calling workgroup that another workgroup will read was a write-through store and has
-// been acknowledged (s_waitcnt) before the arrival is counted.  Returns false when the launch is dead.
-__device__ __forceinline__ bool grid_barrier(const Sync& sy, unsigned& phase, int* s_dead) {
-    ++phase;
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(sy.w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned want = phase * gridDim.x;
-        unsigned spins = 0;
-        while (__hip_atomic_load(sy.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-            if (++spins > sy.spin_limit) {   // some workgroup never arrived: not co-resident (busy GPU)
-                __hip_atomic_store(sy.w + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (sy.status) atomicOr(sy.status, PN2_STATUS_COOP_BARRIER);
-                *s_dead = 1;
-                break;
-            }
-            if ((spins & 63u) == 0 && __hip_atomic_load(sy.w + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-                *s_dead = 1;
-                break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-        }
-    }
-    __syncthreads();
-    return *s_dead == 0;
-}
+// Work queues instead of a static tile-to-workgroup map.  Every phase (a layer's tile list, the pooling pass, ...) has two
+// counters in the caller's sync words: tickets handed out and items DONE.  A workgroup takes items by ticket until the tickets
+// run out, then waits until the phase's done-count is complete -- that wait is the layer barrier.  Nothing requires the
+// launch's workgroups to be co-resident: a workgroup that is scheduled late (a GPU shared with another process, another
+// stream's kernel on some compute units) finds the tickets of the early phases gone, sees them done and catches up; the
+// resident ones never wait for it.  The next ticket is always requested one item ahead (and the first ticket of the next
+// phase before the wait), so a claim's round trip (~1 us, a memory-side atomic) hides behind the item it follows.
+struct Walker {
+    Sync sy;
+    int* s_slot;        // LDS: [0] the ticket being handed to the workgroup, [1] dead
+    unsigned pre;       // thread 0: the ticket requested ahead
+    int phase;
 
-// Last act of a launch: the workgroup that departs last leaves the counters zeroed for the next launch on this stream.
-__device__ __forceinline__ void depart(const Sync& sy) {
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned d = __hip_atomic_fetch_add(sy.w + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (d == gridDim.x - 1) {
-            __hip_atomic_store(sy.w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(sy.w + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __device__ __forceinline__ unsigned* ticket_ctr() const { return sy.w + 4 + 2 * phase; }
+    __device__ __forceinline__ unsigned* done_ctr() const { return sy.w + 5 + 2 * phase; }
+    __device__ __forceinline__ void init(const Sync& s, int* slot) {
+        sy = s;
+        s_slot = slot;
+        phase = 0;
+        pre = 0;
+        if (threadIdx.x == 0) {
+            slot[1] = 0;
+            pre = __hip_atomic_fetch_add(ticket_ctr(), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-}
+    // first ticket of the current phase (requested when the previous phase ran out)
+    __device__ __forceinline__ int take() {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            s_slot[0] = (int)pre;
+            pre = __hip_atomic_fetch_add(ticket_ctr(), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        return s_slot[0];
+    }
+    // the item just worked on is complete (its write-through stores acknowledged): count it, hand out the next ticket
+    __device__ __forceinline__ int done_and_take() {
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(done_ctr(), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_slot[0] = (int)pre;
+            pre = __hip_atomic_fetch_add(ticket_ctr(), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        return s_slot[0];
+    }
+    // Tickets of this phase ran out: request the first ticket of the next phase, then wait until all `nitems` items are done.
+    // Returns false when the launch is dead (a bounded wait ran out: an item's owner vanished -- should not happen).
+    __device__ __forceinline__ bool finish(int nitems) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned* d = done_ctr();
+            ++phase;
+            pre = __hip_atomic_fetch_add(ticket_ctr(), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned spins = 0;
+            while (__hip_atomic_load(d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nitems) {
+                if (++spins > sy.spin_limit) {
+                    __hip_atomic_store(sy.w + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (sy.status) atomicOr(sy.status, PN2_STATUS_COOP_BARRIER);
+                    s_slot[1] = 1;
+                    break;
+                }
+                if ((spins & 63u) == 0 && __hip_atomic_load(sy.w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                    s_slot[1] = 1;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        } else {
+            ++phase;
+        }
+        __syncthreads();
+        return s_slot[1] == 0;
+    }
+    // Last act of a launch: the workgroup that departs last leaves every counter zeroed for the next launch on this stream.
+    __device__ __forceinline__ void depart(int nphases) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned d = __hip_atomic_fetch_add(sy.w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (d == gridDim.x - 1) {
+                for (int k = 0; k < 2 * nphases + 2; ++k) __hip_atomic_store(sy.w + 4 + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(sy.w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+};
 
 // a (first, second) pair of one channel's partials, read past the L2 in one 8-byte load
 __device__ __forceinline__ float2 ld_pair_coh(const float* p) {
@@ -236,107 +284,114 @@ __global__ __launch_bounds__(CT, 1) void chain_coop_fwd_kernel(const FwdArgs) {
     const FwdArgs& a = *(const FwdArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
     __shared__ __attribute__((aligned(16))) float s_coef[ST_ROWS * kMaxC];
-    __shared__ int s_dead;
-    const int tid = (int)threadIdx.x, G = (int)gridDim.x, me = (int)blockIdx.x;
-    if (tid == 0) s_dead = 0;
-    __syncthreads();
+    __shared__ int s_slot[2];
+    const int tid = (int)threadIdx.x;
+    Walker wk;
+    wk.init(a.sy, s_slot);
     const OneSeg st{a.rows};
     const int ntx = (a.rows + TL - 1) / TL;
     const long long pstride = 4ll * ntx;             // two chunks per row tile, two floats per chunk
-    unsigned phase = 0;
     for (int i = 0; i < a.nlayers; ++i) {
         const FwdLayer& L = a.L[i];
-        if (i > 0) {   // the BatchNorm of the layer whose rows this one reads
-            const FwdLayer& P = a.L[i - 1];
-            finalize_fwd(a.partial[(i - 1) & 1], pstride, a.rows, P.cout, P.gamma, P.beta, P.rmean, P.rvar, P.eps, P.momentum,
-                         P.stats, me == 0, s_coef);
-            __syncthreads();
-        }
-        GemmArgs g{};
-        g.A.p = i == 0 ? a.x : a.L[i - 1].y;
-        g.A.ld = i == 0 ? a.ldx : (long long)a.L[i - 1].cout;
-        g.A.rows = a.rows;
-        g.A.cols = L.cin;
-        g.A.coef = i == 0 ? nullptr : s_coef;
-        g.A.cstride = L.cin;
-        g.A.relu = i == 0 ? 0 : a.L[i - 1].relu;
-        g.B.p = L.W;
-        g.B.ld = L.cin;
-        g.B.rows = L.cout;
-        g.B.cols = L.cin;
-        g.M = a.rows;
-        g.N = L.cout;
-        g.K = L.cin;
-        g.C = L.y;
-        g.ldc = L.cout;
-        g.bias = L.bias;
-        g.partial = a.partial[i & 1];
-        g.pstride = pstride;
         const int nty = (L.cout + TL - 1) / TL, nt = ntx * nty;
-        for (int t = me; t < nt; t += G) {
-            const int bx = t / nty, by = t - bx * nty;
-            if (i == 0) {
-                if (L.vec) fwd_tile<TR_PLAIN, true>(g, st, bx, by, lds); else fwd_tile<TR_PLAIN, false>(g, st, bx, by, lds);
-            } else {
-                if (L.vec) fwd_tile<TR_BNRELU, true>(g, st, bx, by, lds); else fwd_tile<TR_BNRELU, false>(g, st, bx, by, lds);
+        int t = wk.take();
+        if (t < nt) {
+            if (i > 0) {   // the BatchNorm of the layer whose rows this one reads; ticket 0's owner keeps the books
+                const FwdLayer& P = a.L[i - 1];
+                finalize_fwd(a.partial[(i - 1) & 1], pstride, a.rows, P.cout, P.gamma, P.beta, P.rmean, P.rvar, P.eps, P.momentum,
+                             P.stats, t == 0, s_coef);
+                __syncthreads();
             }
-            __syncthreads();   // the tile's reduction buffer is the next tile's staging buffer
+            GemmArgs g{};
+            g.A.p = i == 0 ? a.x : a.L[i - 1].y;
+            g.A.ld = i == 0 ? a.ldx : (long long)a.L[i - 1].cout;
+            g.A.rows = a.rows;
+            g.A.cols = L.cin;
+            g.A.coef = i == 0 ? nullptr : s_coef;
+            g.A.cstride = L.cin;
+            g.A.relu = i == 0 ? 0 : a.L[i - 1].relu;
+            g.B.p = L.W;
+            g.B.ld = L.cin;
+            g.B.rows = L.cout;
+            g.B.cols = L.cin;
+            g.M = a.rows;
+            g.N = L.cout;
+            g.K = L.cin;
+            g.C = L.y;
+            g.ldc = L.cout;
+            g.bias = L.bias;
+            g.partial = a.partial[i & 1];
+            g.pstride = pstride;
+            while (t < nt) {
+                const int bx = t / nty, by = t - bx * nty;
+                if (i == 0) {
+                    if (L.vec) fwd_tile<TR_PLAIN, true>(g, st, bx, by, lds); else fwd_tile<TR_PLAIN, false>(g, st, bx, by, lds);
+                } else {
+                    if (L.vec) fwd_tile<TR_BNRELU, true>(g, st, bx, by, lds); else fwd_tile<TR_BNRELU, false>(g, st, bx, by, lds);
+                }
+                t = wk.done_and_take();   // (its barriers also separate the tile's reduction buffer from the next tile's staging)
+            }
         }
-        if (!grid_barrier(a.sy, phase, &s_dead)) return;
+        if (!wk.finish(nt)) return;
     }
-    // ---- the chain's output: max over each group of pool_k rows, or the plain activation
+    // ---- the chain's output: max over each group of pool_k rows, or the plain activation, in items of CT elements
     const FwdLayer& E = a.L[a.nlayers - 1];
-    finalize_fwd(a.partial[(a.nlayers - 1) & 1], pstride, a.rows, E.cout, E.gamma, E.beta, E.rmean, E.rvar, E.eps, E.momentum,
-                 E.stats, me == 0, s_coef);
-    __syncthreads();
     const int C = E.cout, K = a.pool_k;
-    if (K > 1) {
-        const long long total = (long long)(a.rows / K) * C;
-        for (long long e = (long long)me * CT + tid; e < total; e += (long long)G * CT) {
-            const long long gi = e / C;
-            const int c = (int)(e - gi * C);
-            const float mean = s_coef[ST_MEAN * C + c], sc = s_coef[ST_SCALE * C + c], bt = s_coef[ST_BETA * C + c];
-            const float* p = E.y + gi * K * C + c;
-            float best = -__builtin_inff();
-            int bk = 0;
-            for (int k0 = 0; k0 < K; k0 += 8) {
-                float raw[8];
+    const long long total = K > 1 ? (long long)(a.rows / K) * C : (long long)a.rows * C / 4;
+    const int nitems = (int)((total + CT - 1) / CT);
+    int t = wk.take();
+    if (t < nitems) {
+        finalize_fwd(a.partial[(a.nlayers - 1) & 1], pstride, a.rows, E.cout, E.gamma, E.beta, E.rmean, E.rvar, E.eps, E.momentum,
+                     E.stats, t == 0, s_coef);
+        __syncthreads();
+        while (t < nitems) {
+            const long long e = (long long)t * CT + tid;
+            if (e < total) {
+                if (K > 1) {
+                    const long long gi = e / C;
+                    const int c = (int)(e - gi * C);
+                    const float mean = s_coef[ST_MEAN * C + c], sc = s_coef[ST_SCALE * C + c], bt = s_coef[ST_BETA * C + c];
+                    const float* p = E.y + gi * K * C + c;
+                    float best = -__builtin_inff();
+                    int bk = 0;
+                    for (int k0 = 0; k0 < K; k0 += 8) {
+                        float raw[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) raw[u] = ld_coh(p + (long long)(k0 + u < K ? k0 + u : K - 1) * C);
+                        for (int u = 0; u < 8; ++u) raw[u] = ld_coh(p + (long long)(k0 + u < K ? k0 + u : K - 1) * C);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    float v = __builtin_fmaf(raw[u] - mean, sc, bt);
-                    if (E.relu) v = fmaxf(v, 0.f);
-                    if (k0 + u < K && v > best) {
-                        best = v;
-                        bk = k0 + u;
+                        for (int u = 0; u < 8; ++u) {
+                            float v = __builtin_fmaf(raw[u] - mean, sc, bt);
+                            if (E.relu) v = fmaxf(v, 0.f);
+                            if (k0 + u < K && v > best) {
+                                best = v;
+                                bk = k0 + u;
+                            }
+                        }
                     }
+                    a.out[e] = best;
+                    a.arg[e] = bk;
+                } else {
+                    const int c = (int)((e * 4) % C);
+                    const int r = (int)((e * 4) / C);
+                    const float4 v = ld4_coh<true>(E.y, C, r, c, a.rows, C);
+                    float4 o;
+                    o.x = __builtin_fmaf(v.x - s_coef[ST_MEAN * C + c], s_coef[ST_SCALE * C + c], s_coef[ST_BETA * C + c]);
+                    o.y = __builtin_fmaf(v.y - s_coef[ST_MEAN * C + c + 1], s_coef[ST_SCALE * C + c + 1], s_coef[ST_BETA * C + c + 1]);
+                    o.z = __builtin_fmaf(v.z - s_coef[ST_MEAN * C + c + 2], s_coef[ST_SCALE * C + c + 2], s_coef[ST_BETA * C + c + 2]);
+                    o.w = __builtin_fmaf(v.w - s_coef[ST_MEAN * C + c + 3], s_coef[ST_SCALE * C + c + 3], s_coef[ST_BETA * C + c + 3]);
+                    if (E.relu) {
+                        o.x = fmaxf(o.x, 0.f);
+                        o.y = fmaxf(o.y, 0.f);
+                        o.z = fmaxf(o.z, 0.f);
+                        o.w = fmaxf(o.w, 0.f);
+                    }
+                    ((float4*)a.out)[e] = o;
                 }
             }
-            a.out[e] = best;
-            a.arg[e] = bk;
-        }
-    } else {
-        const long long total4 = (long long)a.rows * C / 4;
-        for (long long e = (long long)me * CT + tid; e < total4; e += (long long)G * CT) {
-            const int c = (int)((e * 4) % C);
-            const int r = (int)((e * 4) / C);
-            const float4 v = ld4_coh<true>(E.y, C, r, c, a.rows, C);
-            float4 o;
-            o.x = __builtin_fmaf(v.x - s_coef[ST_MEAN * C + c], s_coef[ST_SCALE * C + c], s_coef[ST_BETA * C + c]);
-            o.y = __builtin_fmaf(v.y - s_coef[ST_MEAN * C + c + 1], s_coef[ST_SCALE * C + c + 1], s_coef[ST_BETA * C + c + 1]);
-            o.z = __builtin_fmaf(v.z - s_coef[ST_MEAN * C + c + 2], s_coef[ST_SCALE * C + c + 2], s_coef[ST_BETA * C + c + 2]);
-            o.w = __builtin_fmaf(v.w - s_coef[ST_MEAN * C + c + 3], s_coef[ST_SCALE * C + c + 3], s_coef[ST_BETA * C + c + 3]);
-            if (E.relu) {
-                o.x = fmaxf(o.x, 0.f);
-                o.y = fmaxf(o.y, 0.f);
-                o.z = fmaxf(o.z, 0.f);
-                o.w = fmaxf(o.w, 0.f);
-            }
-            ((float4*)a.out)[e] = o;
+            t = wk.done_and_take();
         }
     }
-    depart(a.sy);
+    wk.depart(a.nlayers + 1);
 }
 
 // ----------------------------------------------------------------------------------------------------- backward
@@ -383,13 +438,12 @@ __global__ __launch_bounds__(CT, 1) void chain_coop_bwd_kernel(const BwdArgs) {
     const BwdArgs& a = *(const BwdArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
     __shared__ __attribute__((aligned(16))) float s_coef[ST_ROWS * kMaxC];
-    __shared__ int s_dead;
-    const int tid = (int)threadIdx.x, G = (int)gridDim.x, me = (int)blockIdx.x;
-    if (tid == 0) s_dead = 0;
-    __syncthreads();
+    __shared__ int s_slot[2];
+    const int tid = (int)threadIdx.x;
+    Walker wk;
+    wk.init(a.sy, s_slot);
     const OneSeg st{a.rows};
     const int n = a.nlayers;
-    unsigned phase = 0;
     int nblk0;                     // row blocks behind the last layer's BatchNorm-backward partials
     long long pstride0;
     {
@@ -397,7 +451,7 @@ __global__ __launch_bounds__(CT, 1) void chain_coop_bwd_kernel(const BwdArgs) {
         const BwdLayer& E = a.L[n - 1];
         const int C = E.cout, K = a.pool_k;
         const float* cf = E.stats;
-        float* red = lds;          // [2][CT]
+        float* red = lds;
         if (K > 1) {
             // max-pool scatter dz[g K + k][c] = (k == arg[g][c]) ? dout[g][c] : 0 with the sums taken on the way: only the arg-max
             // row of a group carries a gradient
@@ -406,8 +460,11 @@ __global__ __launch_bounds__(CT, 1) void chain_coop_bwd_kernel(const BwdArgs) {
             pstride0 = 2ll * nblk0;
             const int cw = C > 128 ? 256 : C > 64 ? 128 : 64, ng = CT / cw;
             const int tc = tid % cw, tg = tid / cw;
-            for (int blk = me; blk < nblk0; blk += G) {
+            for (int blk = wk.take(); blk < nblk0; blk = wk.done_and_take()) {
                 const int g0 = blk * a.gpb, g1 = g0 + a.gpb < groups ? g0 + a.gpb : groups;
+                if (a.lead)   // the unused leading columns of the chain's input gradient, this block's rows
+                    for (int e = tid; e < (g1 - g0) * K * a.nlead; e += CT)
+                        a.lead[((long long)g0 * K + e / a.nlead) * a.ldlead + e % a.nlead] = 0.0f;
                 for (int c0 = 0; c0 < C; c0 += cw) {
                     const int c = c0 + tc;
                     float s1 = 0.f, s2 = 0.f;
@@ -428,6 +485,7 @@ __global__ __launch_bounds__(CT, 1) void chain_coop_bwd_kernel(const BwdArgs) {
                             for (int k = 0; k < K; ++k) st_coh(&a.dz_last[(base + k) * C + c], k == ka ? gv : 0.0f);
                         }
                     }
+                    __syncthreads();
                     red[tid] = s1;
                     red[CT + tid] = s2;
                     __syncthreads();
@@ -437,7 +495,6 @@ __global__ __launch_bounds__(CT, 1) void chain_coop_bwd_kernel(const BwdArgs) {
                         st_coh(pp, s1);
                         st_coh(pp + 1, s2);
                     }
-                    __syncthreads();
                 }
             }
         } else {
@@ -449,15 +506,17 @@ __global__ __launch_bounds__(CT, 1) void chain_coop_bwd_kernel(const BwdArgs) {
             int cw = 8;
             while (cw < C4 && cw < 256) cw *= 2;
             const int rg = CT / cw, tc = tid % cw, tr = tid / cw;
-            for (int blk = me; blk < nblk0; blk += G) {
+            for (int blk = wk.take(); blk < nblk0; blk = wk.done_and_take()) {
                 const int r0 = blk * RBk, r1 = r0 + RBk < a.rows ? r0 + RBk : a.rows;
+                if (a.lead)
+                    for (int e = tid; e < (r1 - r0) * a.nlead; e += CT) a.lead[((long long)r0 + e / a.nlead) * a.ldlead + e % a.nlead] = 0.0f;
                 for (int q0 = 0; q0 < C4; q0 += cw) {
                     const int c = 4 * (q0 + tc);
                     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
                     if (c < C) {
                         const float4 mean = *(const float4*)(cf + ST_MEAN * C + c), sc = *(const float4*)(cf + ST_SCALE * C + c),
                                      bt = *(const float4*)(cf + ST_BETA * C + c), is = *(const float4*)(cf + ST_INVSTD * C + c);
-                        const float m[4] = {mean.x, mean.y, mean.z, mean.w}, s[4] = {sc.x, sc.y, sc.z, sc.w},
+                        const float m[4] = {mean.x, mean.y, mean.z, mean.w}, sv[4] = {sc.x, sc.y, sc.z, sc.w},
                                     b[4] = {bt.x, bt.y, bt.z, bt.w}, iv[4] = {is.x, is.y, is.z, is.w};
                         for (int r = r0 + tr; r < r1; r += rg) {
                             const float4 yv = *(const float4*)(E.y + (long long)r * C + c);
@@ -465,7 +524,7 @@ __global__ __launch_bounds__(CT, 1) void chain_coop_bwd_kernel(const BwdArgs) {
                             const float yy[4] = {yv.x, yv.y, yv.z, yv.w}, dd[4] = {dv.x, dv.y, dv.z, dv.w};
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
-                                const float t = __builtin_fmaf(yy[j] - m[j], s[j], b[j]);
+                                const float t = __builtin_fmaf(yy[j] - m[j], sv[j], b[j]);
                                 const float gz = (!E.relu || t > 0.f) ? dd[j] : 0.f;
                                 s1[j] += gz;
                                 s2[j] += gz * ((yy[j] - m[j]) * iv[j]);
@@ -489,97 +548,98 @@ __global__ __launch_bounds__(CT, 1) void chain_coop_bwd_kernel(const BwdArgs) {
                             st_coh(pp + 1, t2);
                         }
                     }
-                    __syncthreads();
                 }
             }
         }
-        // the unused leading columns of the chain's input gradient
-        if (a.lead) {
-            const long long total = (long long)a.rows * a.nlead;
-            for (long long e = (long long)me * CT + tid; e < total; e += (long long)G * CT)
-                a.lead[(e / a.nlead) * a.ldlead + e % a.nlead] = 0.0f;
-        }
-        if (!grid_barrier(a.sy, phase, &s_dead)) return;
+        if (!wk.finish(nblk0)) return;
     }
     const int ntx = (a.rows + TL - 1) / TL;
     const long long pstride = 4ll * ntx;   // partials of the input-gradient epilogues: two chunks per row tile
     for (int i = n - 1; i >= 0; --i) {
         const BwdLayer& L = a.L[i];
         const int pi = (n - 1 - i) & 1;    // which partial buffer holds THIS layer's sums
-        if (i == n - 1)
-            finalize_bwd(a.partial[0], pstride0, nblk0, a.rows, L.cout, L.stats, L.dgamma, L.dbeta, me == 0, s_coef);
-        else
-            finalize_bwd(a.partial[pi], pstride, (a.rows + kChunk - 1) / kChunk, a.rows, L.cout, L.stats, L.dgamma, L.dbeta, me == 0, s_coef);
-        __syncthreads();
-        // dY operand: dz through this layer's BatchNorm + ReLU backward
-        Operand dy{};
-        dy.p = L.dz;
-        dy.ld = L.cout;
-        dy.q = L.y;
-        dy.ldq = L.cout;
-        dy.rows = a.rows;
-        dy.cols = L.cout;
-        dy.coef = s_coef;
-        dy.cstride = L.cout;
-        dy.relu = L.relu;
-        // the layer's input as an activation source
-        Operand in{};
-        in.p = i == 0 ? a.x : a.L[i - 1].y;
-        in.ld = i == 0 ? a.ldx : (long long)a.L[i - 1].cout;
-        in.rows = a.rows;
-        in.cols = L.cin;
-        in.coef = i == 0 ? nullptr : a.L[i - 1].stats;
-        in.cstride = L.cin;
-        in.relu = i == 0 ? 0 : a.L[i - 1].relu;
-        GemmArgs gw{};   // dW[cout][cin] = dY^T X over row ranges -> slabs
-        gw.A = dy;
-        gw.B = in;
-        gw.M = L.cout;
-        gw.N = L.cin;
-        gw.K = a.rows;
-        gw.C = L.slab;
-        gw.ldc = L.cin;
-        gw.k_per_split = L.kps;
-        GemmArgs gd{};   // dX[rows][cin - skip] = dY W
-        gd.A = dy;
-        gd.B.p = L.W + L.skip;
-        gd.B.ld = L.cin;
-        gd.B.rows = L.cout;
-        gd.B.cols = L.cin - L.skip;
-        gd.M = a.rows;
-        gd.N = L.cin - L.skip;
-        gd.K = L.cout;
-        gd.C = L.dx;
-        gd.ldc = L.lddx;
-        if (i > 0) {   // the epilogue leaves the BatchNorm-backward sums of layer i - 1
-            gd.partial = a.partial[pi ^ 1];
-            gd.pstride = pstride;
-            gd.ey = a.L[i - 1].y;
-            gd.ldey = a.L[i - 1].cout;
-            gd.ecoef = a.L[i - 1].stats;
-            gd.erelu = a.L[i - 1].relu;
-        }
         const int wx = (L.cout + TL - 1) / TL, wy = (L.cin + TL - 1) / TL;
         const int nw = L.slab ? wx * wy * L.nsplit : 0;
         const int dyt = (L.cin - L.skip + TL - 1) / TL;
         const int nd = L.dx ? ntx * dyt : 0;
-        for (int t = me; t < nw + nd; t += G) {
-            if (t < nd) {          // input-gradient tiles first: the next layer waits for them, the slabs for nobody
-                const int bx = t / dyt, by = t - bx * dyt;
-                if (L.vec_d) dgrad_tile<true>(gd, st, bx, by, lds); else dgrad_tile<false>(gd, st, bx, by, lds);
-            } else {
-                const int u = t - nd, bz = u / (wx * wy), r = u - bz * (wx * wy), bx = r / wy, by = r - bx * wy;
-                if (i == 0) {
-                    if (L.vec_w) wgrad_tile<TR_PLAIN, true>(gw, st, bx, by, bz, lds); else wgrad_tile<TR_PLAIN, false>(gw, st, bx, by, bz, lds);
-                } else {
-                    if (L.vec_w) wgrad_tile<TR_BNRELU, true>(gw, st, bx, by, bz, lds); else wgrad_tile<TR_BNRELU, false>(gw, st, bx, by, bz, lds);
-                }
-            }
+        int t = wk.take();
+        if (t < nw + nd || t == 0) {       // (ticket 0's owner keeps the books -- dgamma, dbeta -- even of a layer without tiles)
+            if (i == n - 1)
+                finalize_bwd(a.partial[0], pstride0, nblk0, a.rows, L.cout, L.stats, L.dgamma, L.dbeta, t == 0, s_coef);
+            else
+                finalize_bwd(a.partial[pi], pstride, (a.rows + kChunk - 1) / kChunk, a.rows, L.cout, L.stats, L.dgamma, L.dbeta, t == 0,
+                             s_coef);
             __syncthreads();
         }
-        if (i > 0 && !grid_barrier(a.sy, phase, &s_dead)) return;
+        if (t < nw + nd) {
+            // dY operand: dz through this layer's BatchNorm + ReLU backward
+            Operand dy{};
+            dy.p = L.dz;
+            dy.ld = L.cout;
+            dy.q = L.y;
+            dy.ldq = L.cout;
+            dy.rows = a.rows;
+            dy.cols = L.cout;
+            dy.coef = s_coef;
+            dy.cstride = L.cout;
+            dy.relu = L.relu;
+            // the layer's input as an activation source
+            Operand in{};
+            in.p = i == 0 ? a.x : a.L[i - 1].y;
+            in.ld = i == 0 ? a.ldx : (long long)a.L[i - 1].cout;
+            in.rows = a.rows;
+            in.cols = L.cin;
+            in.coef = i == 0 ? nullptr : a.L[i - 1].stats;
+            in.cstride = L.cin;
+            in.relu = i == 0 ? 0 : a.L[i - 1].relu;
+            GemmArgs gw{};   // dW[cout][cin] = dY^T X over row ranges -> slabs
+            gw.A = dy;
+            gw.B = in;
+            gw.M = L.cout;
+            gw.N = L.cin;
+            gw.K = a.rows;
+            gw.C = L.slab;
+            gw.ldc = L.cin;
+            gw.k_per_split = L.kps;
+            GemmArgs gd{};   // dX[rows][cin - skip] = dY W
+            gd.A = dy;
+            gd.B.p = L.W + L.skip;
+            gd.B.ld = L.cin;
+            gd.B.rows = L.cout;
+            gd.B.cols = L.cin - L.skip;
+            gd.M = a.rows;
+            gd.N = L.cin - L.skip;
+            gd.K = L.cout;
+            gd.C = L.dx;
+            gd.ldc = L.lddx;
+            if (i > 0) {   // the epilogue leaves the BatchNorm-backward sums of layer i - 1
+                gd.partial = a.partial[pi ^ 1];
+                gd.pstride = pstride;
+                gd.ey = a.L[i - 1].y;
+                gd.ldey = a.L[i - 1].cout;
+                gd.ecoef = a.L[i - 1].stats;
+                gd.erelu = a.L[i - 1].relu;
+            }
+            while (t < nw + nd) {
+                if (t < nd) {          // input-gradient tiles first: the next layer waits for them, the slabs for nobody
+                    const int bx = t / dyt, by = t - bx * dyt;
+                    if (L.vec_d) dgrad_tile<true>(gd, st, bx, by, lds); else dgrad_tile<false>(gd, st, bx, by, lds);
+                } else {
+                    const int u = t - nd, bz = u / (wx * wy), r = u - bz * (wx * wy), bx = r / wy, by = r - bx * wy;
+                    if (i == 0) {
+                        if (L.vec_w) wgrad_tile<TR_PLAIN, true>(gw, st, bx, by, bz, lds); else wgrad_tile<TR_PLAIN, false>(gw, st, bx, by, bz, lds);
+                    } else {
+                        if (L.vec_w) wgrad_tile<TR_BNRELU, true>(gw, st, bx, by, bz, lds); else wgrad_tile<TR_BNRELU, false>(gw, st, bx, by, bz, lds);
+                    }
+                }
+                t = wk.done_and_take();
+            }
+        }
+        // (every tile, not just the input gradient's: a straggling weight-gradient tile still reads the dz buffer that the next
+        // layer's input-gradient tiles overwrite)
+        if (i > 0 && !wk.finish(nw + nd)) return;
     }
-    depart(a.sy);
+    wk.depart(n + 1);
 }
 
 inline bool al16(const void* p) { return ((uintptr_t)p & 15) == 0; }

@@ -436,9 +436,14 @@ def test_two_rank_gradient_equals_sequential_emulation(pn2, n, trees, depth):
     procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, n, trees, depth, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=600) for _ in procs]
+    try:
+        res = [q.get(timeout=240) for _ in procs]       # (well inside the GPU box's 7-minute silence limit)
+    except Exception:
+        for p in procs:
+            p.kill()
+        raise
     for p in procs:
-        p.join(timeout=120)
+        p.join(timeout=60)
         assert p.exitcode == 0
     params0 = [torch.from_numpy(a) for a in next(r[0] for r in res if r[0] is not None)]
     flats = [torch.from_numpy(r[1]) for r in res]
