@@ -108,7 +108,7 @@ struct Walker {
                     s_slot[1] = 1;
                     break;
                 }
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(4);
             }
         } else {
             ++phase;
@@ -135,6 +135,7 @@ __device__ __forceinline__ float2 ld_pair_coh(const float* p) {
     return make_float2(__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32)));
 }
 
+constexpr int kFly = 16;   // partial pairs a lane has in flight in the merges
 // lanes per channel for the partial merges: a power of two <= 64 so that a channel's lanes share a wavefront
 __device__ __forceinline__ int lanes_per_channel(int C, int nchunk) {
     int t = 1;
@@ -151,7 +152,7 @@ __device__ __forceinline__ double group_sum_f64(double v, int T) {
 // ([ST_ROWS][C]).  Every workgroup does this for itself; `writer` also stores the block and updates the running statistics
 // like nn.BatchNorm.  float64, one pass: with the first chunk's mean as pivot p and d_k = m_k - p,
 //   mean = p + sum(n_k d_k) / N,   var = (sum M2_k + sum n_k d_k^2 - N (mean - p)^2) / N        (Chan's merge, single pass)
-__device__ void finalize_fwd(const float* __restrict__ partial, long long pstride, int rows, int C, const float* __restrict__ gamma,
+__device__ __forceinline__ void finalize_fwd(const float* __restrict__ partial, long long pstride, int rows, int C, const float* __restrict__ gamma,
                              const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar, float eps,
                              float momentum, float* __restrict__ gstats, bool writer, float* __restrict__ coef) {
     const int nchunk = (rows + kChunk - 1) / kChunk;
@@ -160,26 +161,27 @@ __device__ void finalize_fwd(const float* __restrict__ partial, long long pstrid
         const int c = c0 + tid / T, sub = tid % T;
         const bool ok = c < C;
         const float* pc = partial + (long long)(ok ? c : 0) * pstride;
-        const float pivot = ld_pair_coh(pc).x;
+        // (no dummy loads for idle lanes or short columns: these loads go past the L2, and a thousand of them on ONE address
+        // serialise at the memory side -- 7-14 us per merge measured, tools/diag_coop.py)
+        const float pivot = ok ? ld_pair_coh(pc).x : 0.0f;
+        const int mine = ok ? (nchunk - sub + T - 1) / T : 0;   // this lane's chunks: sub, sub + T, ...
         double a = 0.0, b = 0.0, q = 0.0;
-        for (int k0 = sub; k0 < nchunk; k0 += 4 * T) {   // four independent loads in flight
-            float2 v[4];
+        for (int j0 = 0; j0 < mine; j0 += kFly) {   // up to kFly independent loads in flight
+            float2 v[kFly];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int k = k0 + u * T;
-                v[u] = ld_pair_coh(pc + 2 * (k < nchunk ? k : sub));
-            }
+            for (int u = 0; u < kFly; ++u)
+                if (j0 + u < mine) v[u] = ld_pair_coh(pc + 2 * (sub + (j0 + u) * T));
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int k = k0 + u * T;
-                if (k >= nchunk) break;
-                const int left = rows - k * kChunk;
-                const double n = (double)(left < kChunk ? left : kChunk);
-                const double d = (double)v[u].x - (double)pivot;
-                a += n * d;
-                b += n * d * d;
-                q += (double)v[u].y;
-            }
+            for (int u = 0; u < kFly; ++u)
+                if (j0 + u < mine) {
+                    const int k = sub + (j0 + u) * T;
+                    const int left = rows - k * kChunk;
+                    const double n = (double)(left < kChunk ? left : kChunk);
+                    const double d = (double)v[u].x - (double)pivot;
+                    a += n * d;
+                    b += n * d * d;
+                    q += (double)v[u].y;
+                }
         }
         a = group_sum_f64(a, T);
         b = group_sum_f64(b, T);
@@ -212,24 +214,23 @@ __device__ void finalize_fwd(const float* __restrict__ partial, long long pstrid
 // Backward coefficients of one layer from channel-major (s1, s2) pairs over `nblk` row blocks: a = s1 / N, b = invstd s2 / N
 // (what TR_DY needs next to the forward's mean / scale / beta, copied here from the layer's stored block) -> LDS block;
 // `writer` also accumulates dbeta += s1, dgamma += s2 and stores (a, b).
-__device__ void finalize_bwd(const float* __restrict__ partial, long long pstride, int nblk, int rows, int C, float* __restrict__ gstats,
+__device__ __forceinline__ void finalize_bwd(const float* __restrict__ partial, long long pstride, int nblk, int rows, int C, float* __restrict__ gstats,
                              float* __restrict__ dgamma, float* __restrict__ dbeta, bool writer, float* __restrict__ coef) {
     const int T = lanes_per_channel(C, nblk), per = CT / T, tid = (int)threadIdx.x;
     for (int c0 = 0; c0 < C; c0 += per) {
         const int c = c0 + tid / T, sub = tid % T;
         const bool ok = c < C;
         const float* pc = partial + (long long)(ok ? c : 0) * pstride;
+        const int mine = ok ? (nblk - sub + T - 1) / T : 0;
         double s1 = 0.0, s2 = 0.0;
-        for (int k0 = sub; k0 < nblk; k0 += 4 * T) {
-            float2 v[4];
+        for (int j0 = 0; j0 < mine; j0 += kFly) {
+            float2 v[kFly];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int k = k0 + u * T;
-                v[u] = ld_pair_coh(pc + 2 * (k < nblk ? k : sub));
-            }
+            for (int u = 0; u < kFly; ++u)
+                if (j0 + u < mine) v[u] = ld_pair_coh(pc + 2 * (sub + (j0 + u) * T));
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (k0 + u * T < nblk) {
+            for (int u = 0; u < kFly; ++u)
+                if (j0 + u < mine) {
                     s1 += (double)v[u].x;
                     s2 += (double)v[u].y;
                 }
@@ -271,7 +272,13 @@ struct FwdArgs {
     int32_t* arg;
     float* partial[2];
     Sync sy;
+    unsigned long long* diag;   // tuning aid (PN2_COOP_DIAG): [workgroup][phase][8] 100 MHz time stamps, or null
 };
+
+#define COOP_STAMP(slot)                                                                                      \
+    do {                                                                                                      \
+        if (a.diag && tid == 0) a.diag[((long long)blockIdx.x * 8 + dphase) * 8 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
 
 template <int A_KIND, bool VEC>
 __device__ __forceinline__ void fwd_tile(const GemmArgs& g, const OneSeg& st, int bx, int by, float* lds) {
@@ -291,10 +298,15 @@ __global__ __launch_bounds__(CT, 1) void chain_coop_fwd_kernel(const FwdArgs) {
     const OneSeg st{a.rows};
     const int ntx = (a.rows + TL - 1) / TL;
     const long long pstride = 4ll * ntx;             // two chunks per row tile, two floats per chunk
+    int dphase = 0;
     for (int i = 0; i < a.nlayers; ++i) {
         const FwdLayer& L = a.L[i];
         const int nty = (L.cout + TL - 1) / TL, nt = ntx * nty;
+        dphase = i;
+        COOP_STAMP(0);
         int t = wk.take();
+        COOP_STAMP(1);
+        if (a.diag && tid == 0) a.diag[((long long)blockIdx.x * 8 + dphase) * 8 + 7] = (unsigned long long)t;
         if (t < nt) {
             if (i > 0) {   // the BatchNorm of the layer whose rows this one reads; ticket 0's owner keeps the books
                 const FwdLayer& P = a.L[i - 1];
@@ -322,6 +334,7 @@ __global__ __launch_bounds__(CT, 1) void chain_coop_fwd_kernel(const FwdArgs) {
             g.bias = L.bias;
             g.partial = a.partial[i & 1];
             g.pstride = pstride;
+            COOP_STAMP(2);
             while (t < nt) {
                 const int bx = t / nty, by = t - bx * nty;
                 if (i == 0) {
@@ -329,21 +342,29 @@ __global__ __launch_bounds__(CT, 1) void chain_coop_fwd_kernel(const FwdArgs) {
                 } else {
                     if (L.vec) fwd_tile<TR_BNRELU, true>(g, st, bx, by, lds); else fwd_tile<TR_BNRELU, false>(g, st, bx, by, lds);
                 }
+                COOP_STAMP(3);
                 t = wk.done_and_take();   // (its barriers also separate the tile's reduction buffer from the next tile's staging)
+                COOP_STAMP(4);
             }
         }
+        COOP_STAMP(5);
         if (!wk.finish(nt)) return;
+        COOP_STAMP(6);
     }
+    dphase = a.nlayers;
+    COOP_STAMP(0);
     // ---- the chain's output: max over each group of pool_k rows, or the plain activation, in items of CT elements
     const FwdLayer& E = a.L[a.nlayers - 1];
     const int C = E.cout, K = a.pool_k;
     const long long total = K > 1 ? (long long)(a.rows / K) * C : (long long)a.rows * C / 4;
     const int nitems = (int)((total + CT - 1) / CT);
     int t = wk.take();
+    COOP_STAMP(1);
     if (t < nitems) {
         finalize_fwd(a.partial[(a.nlayers - 1) & 1], pstride, a.rows, E.cout, E.gamma, E.beta, E.rmean, E.rvar, E.eps, E.momentum,
                      E.stats, t == 0, s_coef);
         __syncthreads();
+        COOP_STAMP(2);
         while (t < nitems) {
             const long long e = (long long)t * CT + tid;
             if (e < total) {
@@ -354,12 +375,12 @@ __global__ __launch_bounds__(CT, 1) void chain_coop_fwd_kernel(const FwdArgs) {
                     const float* p = E.y + gi * K * C + c;
                     float best = -__builtin_inff();
                     int bk = 0;
-                    for (int k0 = 0; k0 < K; k0 += 8) {
-                        float raw[8];
+                    for (int k0 = 0; k0 < K; k0 += 32) {   // a whole group's rows in flight (each load is a trip past the L2)
+                        float raw[32];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) raw[u] = ld_coh(p + (long long)(k0 + u < K ? k0 + u : K - 1) * C);
+                        for (int u = 0; u < 32; ++u) raw[u] = ld_coh(p + (long long)(k0 + u < K ? k0 + u : K - 1) * C);
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) {
+                        for (int u = 0; u < 32; ++u) {
                             float v = __builtin_fmaf(raw[u] - mean, sc, bt);
                             if (E.relu) v = fmaxf(v, 0.f);
                             if (k0 + u < K && v > best) {
@@ -388,9 +409,12 @@ __global__ __launch_bounds__(CT, 1) void chain_coop_fwd_kernel(const FwdArgs) {
                     ((float4*)a.out)[e] = o;
                 }
             }
+            COOP_STAMP(3);
             t = wk.done_and_take();
+            COOP_STAMP(4);
         }
     }
+    COOP_STAMP(5);
     wk.depart(a.nlayers + 1);
 }
 
@@ -717,6 +741,7 @@ int forward(const FwdCall& c) {
     }
     const int cap = max_wg(c.ctl);
     const int G = tiles < cap ? tiles : cap;
+    if (const char* e = getenv("PN2_COOP_DIAG")) a.diag = (unsigned long long*)strtoull(e, nullptr, 0);   // device buffer, 256 x 8 x 8 u64
     PN2_LAUNCH("chain_coop_fwd", bytes, flops, chain_coop_fwd_kernel, dim3(G), dim3(CT), c.stream, a);
     PN2_LAUNCH_CHECK();
     return 0;
