@@ -7,7 +7,7 @@ namespace pn2 {
 namespace coop {
 
 constexpr int kMaxLayers = 4;     // layers per chain
-constexpr int kMaxC = 1024;       // widest BatchNorm layer whose coefficient block fits the LDS copy
+constexpr int kMaxC = 512;        // widest BatchNorm layer whose coefficient block fits the LDS copy
 
 struct FwdCall {
     const float* x;

@@ -28,12 +28,13 @@
 
 namespace {
 
-constexpr int CT = NT * 4;                          // threads per workgroup: four K-teams
-constexpr int TL = 64;                              // tile edge
+constexpr int NTT = 64;                             // threads per K-team: one wavefront (the 32 x 32 tile of mlp_tile.h)
+constexpr int CT = NTT * 4;                         // threads per workgroup: four K-teams
+constexpr int TL = 32;                              // tile edge
 constexpr int kLdsFloats = 4 * 4 * BK * (TL + 4);   // staging buffers of the four teams (re-used as their reduction buffer)
 constexpr int kMaxL = pn2::coop::kMaxLayers;
 constexpr int kMaxC = pn2::coop::kMaxC;
-constexpr int kChunk = TL / 2;                      // rows per statistics chunk (one wavefront's rows of a tile)
+constexpr int kChunk = TL;                          // rows per statistics chunk (one wavefront's rows of a tile)
 
 struct Sync {
     unsigned* w;        // [0] departures, [1] dead flag, phase p: [4 + 2 p] tickets handed out, [5 + 2 p] items done
@@ -135,7 +136,7 @@ __device__ __forceinline__ float2 ld_pair_coh(const float* p) {
     return make_float2(__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32)));
 }
 
-constexpr int kFly = 16;   // partial pairs a lane has in flight in the merges
+constexpr int kFly = 32;   // partial pairs a lane has in flight in the merges
 // lanes per channel for the partial merges: a power of two <= 64 so that a channel's lanes share a wavefront
 __device__ __forceinline__ int lanes_per_channel(int C, int nchunk) {
     int t = 1;
@@ -282,12 +283,12 @@ struct FwdArgs {
 
 template <int A_KIND, bool VEC>
 __device__ __forceinline__ void fwd_tile(const GemmArgs& g, const OneSeg& st, int bx, int by, float* lds) {
-    gemm_body<true, A_KIND, true, TR_PLAIN, EPI_FWD, TL, VEC, 4, false, false, true>(g, st, bx, by, 0, lds);
+    gemm_body<true, A_KIND, true, TR_PLAIN, EPI_FWD, TL, VEC, 4, false, false, true, NTT>(g, st, bx, by, 0, lds);
 }
 
 // (The argument block is read through the kernarg segment pointer: a by-value struct indexed with a run-time layer number
 // would be copied to private memory first -- 430 bytes of scratch per lane and every pointer in it a vector register.)
-__global__ __launch_bounds__(CT, 1) void chain_coop_fwd_kernel(const FwdArgs) {
+__global__ __launch_bounds__(CT, 2) void chain_coop_fwd_kernel(const FwdArgs) {
     const FwdArgs& a = *(const FwdArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
     __shared__ __attribute__((aligned(16))) float s_coef[ST_ROWS * kMaxC];
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(CT, 1) void chain_coop_fwd_kernel(const FwdArgs) {
     wk.init(a.sy, s_slot);
     const OneSeg st{a.rows};
     const int ntx = (a.rows + TL - 1) / TL;
-    const long long pstride = 4ll * ntx;             // two chunks per row tile, two floats per chunk
+    const long long pstride = 2ll * ntx;             // one chunk per row tile, two floats per chunk
     int dphase = 0;
     for (int i = 0; i < a.nlayers; ++i) {
         const FwdLayer& L = a.L[i];
@@ -451,14 +452,14 @@ struct BwdArgs {
 
 template <bool VEC>
 __device__ __forceinline__ void dgrad_tile(const GemmArgs& g, const OneSeg& st, int bx, int by, float* lds) {
-    gemm_body<true, TR_DY, false, TR_PLAIN, EPI_STORE, TL, VEC, 4, false, false, true>(g, st, bx, by, 0, lds);
+    gemm_body<true, TR_DY, false, TR_PLAIN, EPI_STORE, TL, VEC, 4, false, false, true, NTT>(g, st, bx, by, 0, lds);
 }
 template <int B_KIND, bool VEC>
 __device__ __forceinline__ void wgrad_tile(const GemmArgs& g, const OneSeg& st, int bx, int by, int bz, float* lds) {
-    gemm_body<false, TR_DY, false, B_KIND, EPI_SLAB, TL, VEC, 4, false, false, true>(g, st, bx, by, bz, lds);
+    gemm_body<false, TR_DY, false, B_KIND, EPI_SLAB, TL, VEC, 4, false, false, true, NTT>(g, st, bx, by, bz, lds);
 }
 
-__global__ __launch_bounds__(CT, 1) void chain_coop_bwd_kernel(const BwdArgs) {
+__global__ __launch_bounds__(CT, 2) void chain_coop_bwd_kernel(const BwdArgs) {
     const BwdArgs& a = *(const BwdArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
     __shared__ __attribute__((aligned(16))) float s_coef[ST_ROWS * kMaxC];
@@ -578,7 +579,7 @@ __global__ __launch_bounds__(CT, 1) void chain_coop_bwd_kernel(const BwdArgs) {
         if (!wk.finish(nblk0)) return;
     }
     const int ntx = (a.rows + TL - 1) / TL;
-    const long long pstride = 4ll * ntx;   // partials of the input-gradient epilogues: two chunks per row tile
+    const long long pstride = 2ll * ntx;   // partials of the input-gradient epilogues: one chunk per row tile
     for (int i = n - 1; i >= 0; --i) {
         const BwdLayer& L = a.L[i];
         const int pi = (n - 1 - i) & 1;    // which partial buffer holds THIS layer's sums
@@ -676,9 +677,9 @@ Sync make_sync(const pn2_coop* ctl) {
     return s;
 }
 int max_wg(const pn2_coop* ctl) {
-    int m = ctl->max_workgroups > 0 ? ctl->max_workgroups : 256;
+    int m = ctl->max_workgroups > 0 ? ctl->max_workgroups : 128;
     if (const char* e = getenv("PN2_COOP_MAX_WG")) m = atoi(e) > 0 ? atoi(e) : m;   // tuning aid
-    return m < 1 ? 1 : (m > 256 ? 256 : m);
+    return m < 1 ? 1 : (m > 1024 ? 1024 : m);
 }
 
 }  // namespace
@@ -702,7 +703,7 @@ bool shapes_ok(int rows, const pn2_mlp_layer* layers, int nlayers, int pool_k) {
 
 void plan_slabs(int rows, int cout, int cin, int* kps, int* nsplit) {
     const int tiles = ceil_div(cout, TL) * ceil_div(cin, TL);
-    int want = 160 / tiles;                       // ~160 weight-gradient tiles per layer next to the input-gradient tiles
+    int want = 256 / tiles;                       // ~256 weight-gradient tiles per layer next to the input-gradient tiles
     if (want < 1) want = 1;
     int k = ceil_div(ceil_div(rows, want), 4 * BK) * 4 * BK;   // whole K-tiles for each of the four teams
     if (k < 4 * BK) k = 4 * BK;

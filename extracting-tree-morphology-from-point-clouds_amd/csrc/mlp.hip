@@ -1042,7 +1042,7 @@ inline int pick_tile(int M, int N, int nsplit) {
 
 // Row-tiled roles (forward, dgrad): grid.x = row tiles of the segments; wgrad: grid.z = reduction ranges of the segments
 // (`g.k_per_split` rows each), grid.x tiles the output rows (= cout).
-template <bool A_T, int A_KIND, bool B_T, int B_KIND, int EPI, int TILE, bool VEC, int TEAMS = 1, bool BF16 = false>
+template <bool A_T, int A_KIND, bool B_T, int B_KIND, int EPI, int TILE, bool VEC, int TEAMS = 1, bool BF16 = false, int NTT = NT>
 int launch_gemm_tv(GemmArgs& g, const Segs& S, hipStream_t s, int* nblk_out) {
     int nblk = 0;
     const SegTable st = make_table(S, EPI == EPI_SLAB ? g.k_per_split : TILE, &nblk);
@@ -1059,11 +1059,12 @@ int launch_gemm_tv(GemmArgs& g, const Segs& S, hipStream_t s, int* nblk_out) {
     const double extra = (closing ? 1.0 : 0.0) + ((EPI == EPI_STORE && g.partial) ? 1.0 : 0.0);   // C read, ey read
     const double bytes = 4.0 * (mk + kn + (double)g.M * g.N * ((EPI == EPI_SLAB ? nblk : 1) + extra));
     if (closing)
-        PN2_LAUNCH(name, bytes, 2.0 * g.M * g.N * g.K, (gemm_kernel<A_T, A_KIND, B_T, B_KIND, EPI, TILE, VEC, TEAMS, BF16, EPI == EPI_STORE>),
-                   grid, dim3(NT * TEAMS), s, g, st);
+        PN2_LAUNCH(name, bytes, 2.0 * g.M * g.N * g.K,
+                   (gemm_kernel<A_T, A_KIND, B_T, B_KIND, EPI, TILE, VEC, TEAMS, BF16, EPI == EPI_STORE, NTT>), grid, dim3(NTT * TEAMS), s, g,
+                   st);
     else
-        PN2_LAUNCH(name, bytes, 2.0 * g.M * g.N * g.K, (gemm_kernel<A_T, A_KIND, B_T, B_KIND, EPI, TILE, VEC, TEAMS, BF16>), grid,
-                   dim3(NT * TEAMS), s, g, st);
+        PN2_LAUNCH(name, bytes, 2.0 * g.M * g.N * g.K, (gemm_kernel<A_T, A_KIND, B_T, B_KIND, EPI, TILE, VEC, TEAMS, BF16, false, NTT>),
+                   grid, dim3(NTT * TEAMS), s, g, st);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
@@ -1078,6 +1079,13 @@ int launch_gemm(GemmArgs& g, const Segs& S, int tile, hipStream_t s, int* nblk_o
     if (tile == 128)
         return vec ? launch_gemm_tv<A_T, A_KIND, B_T, B_KIND, EPI, 128, true>(g, S, s, nblk_out)
                    : launch_gemm_tv<A_T, A_KIND, B_T, B_KIND, EPI, 128, false>(g, S, s, nblk_out);
+    // The smallest problems (a deep level: <= 128 tiles of 64 x 64): 32 x 32 tiles whose four K-teams are ONE wavefront each -- four
+    // times the workgroups, i.e. four times the compute units whose matrix cores take part (chunks of statistics stay 32 rows, so
+    // the callers' 64-tile bookkeeping -- two chunks per 64 rows -- still describes the partials).
+    if (EPI != EPI_SLAB && S.nseg == 1 && !g.accumulate && g.K >= 8 * BK && (long long)grid_blocks(g.M, g.N, 64) <= 128 &&
+        !getenv("PN2_NO_TILE32"))
+        return vec ? launch_gemm_tv<A_T, A_KIND, B_T, B_KIND, EPI, 32, true, 4, false, 64>(g, S, s, nblk_out)
+                   : launch_gemm_tv<A_T, A_KIND, B_T, B_KIND, EPI, 32, false, 4, false, 64>(g, S, s, nblk_out);
     // small problem with a long contraction: split K over four teams inside the workgroup
     if (EPI != EPI_SLAB && g.K >= 8 * BK && (long long)grid_blocks(g.M, g.N, 64) <= 512)
         return vec ? launch_gemm_tv<A_T, A_KIND, B_T, B_KIND, EPI, 64, true, 4>(g, S, s, nblk_out)

@@ -372,10 +372,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[N
 // cooperative chain kernels walk tile lists).  COH: the A operand and the outputs cross workgroups of ONE launch (coherent
 // loads, write-through stores, see ld4_coh); the teams' early exit becomes a fall-through (every thread reaches the caller's
 // barrier).  `lds`: TEAMS * 4 * BK * (TILE + 4) floats.
-template <bool A_T, int A_KIND, bool B_T, int B_KIND, int EPI, int TILE, bool VEC, int TEAMS, bool BF16, bool ACC, bool COH, class TAB>
+// NTT: threads per K-team -- 256 (four wavefronts, 2 x 2 over the tile), or 64 for the 32 x 32 tile of the smallest problems:
+// ONE wavefront per team, so that a layer of a few hundred rows still spreads over a few hundred compute units (a 64-tile
+// pins 2 * 64 * 64 * K flops to one unit's matrix cores: 1.7 us per K-tile with four teams on it, tools/diag_coop.py).
+template <bool A_T, int A_KIND, bool B_T, int B_KIND, int EPI, int TILE, bool VEC, int TEAMS, bool BF16, bool ACC, bool COH, int NTT, class TAB>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g0, const TAB& st, const int BX, const int BY, const int BZ,
                                           float* __restrict__ lds) {
-    constexpr int LD = TILE + 4, WT = TILE / 2, NI = WT / 32;
+    static_assert(NTT == NT || (NTT == 64 && TILE == 32 && TEAMS > 1), "single-wavefront teams are for the 32-tile");
+    constexpr int LD = TILE + 4, WT = NTT == 64 ? TILE : TILE / 2, NI = WT / 32;
     // Which rows does this workgroup own?  Row tiles (forward, dgrad) and reduction ranges (wgrad) never straddle a
     // segment: the operands' row limit, the output's row limit and the BatchNorm coefficient blocks are those of the
     // block's segment (st.nseg == 1: the whole matrix, coefficient block 0).
@@ -396,9 +400,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g0, const TAB& st, con
     if (g.A.coef) g.A.coef += (long long)seg * ST_ROWS * g.A.cstride;
     if (g.B.coef) g.B.coef += (long long)seg * ST_ROWS * g.B.cstride;
     if (EPI == EPI_STORE && g.ecoef) g.ecoef += (long long)seg * ST_ROWS * g.N;
-    static_assert(TEAMS == 1 || TILE == 64, "teams are for the small-problem tile");
+    static_assert(TEAMS == 1 || TILE == 64 || TILE == 32, "teams are for the small-problem tiles");
     // one LDS object (it is re-used as the teams' reduction buffer): [team][A|B][buffer][BK * LD]
-    const int team = (int)threadIdx.x / NT, tid = (int)threadIdx.x % NT;
+    const int team = (int)threadIdx.x / NTT, tid = (int)threadIdx.x % NTT;
     float(*As)[BK * LD] = (float(*)[BK * LD])(lds + (team * 4 + 0) * BK * LD);
     float(*Bs)[BK * LD] = (float(*)[BK * LD])(lds + (team * 4 + 2) * BK * LD);
 
@@ -432,8 +436,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g0, const TAB& st, con
             }
     }
 
-    Stager<A_T, A_KIND, TILE, VEC, NT, COH> sa;
-    Stager<B_T, B_KIND, TILE, VEC> sb;
+    Stager<A_T, A_KIND, TILE, VEC, NTT, COH> sa;
+    Stager<B_T, B_KIND, TILE, VEC, NTT> sb;
     sa.tid = tid;
     sb.tid = tid;
     sa.prepare(g.A, m0);
@@ -457,7 +461,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g0, const TAB& st, con
         // The K-tile's MFMAs are issued in NP groups; after each group one pass of the NEXT tile is staged into the
         // other LDS buffer, so the staging VALU/LDS work sits in the shadow of the (asynchronous, 64-cycle) MFMAs
         // instead of forming a separate phase during which this wave's matrix pipe idles.
-        constexpr int NP = TILE * BK / (4 * NT), KQ = BK / NP;
+        constexpr int NP = TILE * BK / (4 * NTT), KQ = BK / NP;
         if constexpr (BF16) {
             static_assert(!BF16 || BK == 16, "one 32x32x16 MFMA consumes a whole K-tile");
             // lane (r = lane & 31, h = lane >> 5) supplies A[row r][k = 8h + e] and B[k = 8h + e][col r], e = 0..7
@@ -507,17 +511,17 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g0, const TAB& st, con
     if (TEAMS > 1) {
         // sum the teams' partial tiles through LDS (the staging buffers are free now); team 0 runs the epilogue
         float* red = lds;   // (TEAMS - 1) x NT x 16 floats = 48 KiB of the 68 KiB
-        static_assert(TEAMS == 1 || (TEAMS - 1) * 16 * NT <= TEAMS * 4 * BK * LD, "reduction buffer must fit");
+        static_assert(TEAMS == 1 || (TEAMS - 1) * 16 * NTT <= TEAMS * 4 * BK * LD, "reduction buffer must fit");
         if (team > 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) red[((team - 1) * 16 + r) * NT + tid] = acc[0][0][r];
+            for (int r = 0; r < 16; ++r) red[((team - 1) * 16 + r) * NTT + tid] = acc[0][0][r];
         }
         __syncthreads();
         if (team == 0) {
 #pragma unroll
             for (int t = 0; t < TEAMS - 1; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[0][0][r] += red[(t * 16 + r) * NT + tid];
+                for (int r = 0; r < 16; ++r) acc[0][0][r] += red[(t * 16 + r) * NTT + tid];
         }
     }
     if (TEAMS == 1 || team == 0)
@@ -525,12 +529,13 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g0, const TAB& st, con
 }
 
 // One tile per workgroup: the launch grid is the tile grid.
-template <bool A_T, int A_KIND, bool B_T, int B_KIND, int EPI, int TILE, bool VEC, int TEAMS, bool BF16 = false, bool ACC = false>
-__global__ __launch_bounds__(NT * TEAMS, (TEAMS > 1 ? 1 : (EPI == EPI_STORE ? 2 : 3))) void gemm_kernel(const GemmArgs g0,
-                                                                                                         const SegTable st) {
+template <bool A_T, int A_KIND, bool B_T, int B_KIND, int EPI, int TILE, bool VEC, int TEAMS, bool BF16 = false, bool ACC = false,
+          int NTT = NT>
+__global__ __launch_bounds__(NTT * TEAMS, (NTT == 64 ? 4 : TEAMS > 1 ? 1 : (EPI == EPI_STORE ? 2 : 3))) void gemm_kernel(const GemmArgs g0,
+                                                                                                                        const SegTable st) {
     __shared__ __attribute__((aligned(16))) float lds[TEAMS * 4 * BK * (TILE + 4)];
-    gemm_body<A_T, A_KIND, B_T, B_KIND, EPI, TILE, VEC, TEAMS, BF16, ACC, false>(g0, st, (int)blockIdx.x, (int)blockIdx.y,
-                                                                                 (int)blockIdx.z, lds);
+    gemm_body<A_T, A_KIND, B_T, B_KIND, EPI, TILE, VEC, TEAMS, BF16, ACC, false, NTT>(g0, st, (int)blockIdx.x, (int)blockIdx.y,
+                                                                                      (int)blockIdx.z, lds);
 }
 
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }

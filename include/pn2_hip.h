@@ -363,23 +363,25 @@ typedef struct pn2_wgrad_tasks {
 
 /* Cooperative chain launches (the deep levels).  A chain of a few hundred to a few thousand rows is ~25 launches of 5-25 us
  * each way -- GEMM, BatchNorm finalize, GEMM, ... -- whose time is launch ramp and drain, not work.  With a non-NULL `coop`
- * such a chain (train mode, one segment, every layer a BatchNorm layer, rows <= PN2_COOP_MAX_ROWS) runs as ONE persistent
- * launch per direction: every workgroup walks the layers' 64 x 64 tile lists, layers are separated by a grid-wide arrival
- * counter instead of a kernel boundary, tiles that cross workgroups are stored write-through and read past the (per-XCD,
+ * such a chain (train mode, one segment, every layer a BatchNorm layer, rows <= PN2_COOP_MAX_ROWS -- the default is where it was
+ * measured to win; the environment variable PN2_COOP_MAX_ROWS overrides it) runs as ONE persistent
+ * launch per direction: workgroups take the layers' 32 x 32 tiles from work queues, layers are separated by the queues' done
+ * counts instead of a kernel boundary, tiles that cross workgroups are stored write-through and read past the (per-XCD,
  * mutually incoherent) L2, and every workgroup derives the BatchNorm coefficients it needs from the tile epilogues'
  * partials itself (no finalize launches).  Same arithmetic per element as the launch-per-layer path (same tile code).
  *   sync    >= 64 device uint32 words, ZEROED ONCE by the caller and then left alone; one buffer per stream on which chains
  *           run (launches on one stream are ordered; the kernels leave the words zeroed again when they finish)
  *   status  the sticky PN2_STATUS_* word (PN2_STATUS_COOP_BARRIER: a barrier timed out after spin_limit polls -- the launch
  *           drains, its results are garbage; the caller re-zeroes `sync` before the next launch)
- * All workgroups of a launch must be co-resident (at most one per compute unit, max_workgroups <= 256; 0 = default).
+ * Nothing requires the launch's workgroups to be co-resident (work queues; a GPU shared with another process is fine).
+ * max_workgroups: cap of the launch's grid (0 = default 128: more pollers make every barrier slower).
  * NULL: always the launch-per-layer path. */
-#define PN2_COOP_MAX_ROWS 16384
+#define PN2_COOP_MAX_ROWS 256
 typedef struct pn2_coop {
     uint32_t *sync;
     int32_t *status;
     uint32_t spin_limit;     /* 0 = default (1 << 22 polls, seconds) */
-    int32_t max_workgroups;  /* 0 = default (256) */
+    int32_t max_workgroups;  /* 0 = default (128) */
 } pn2_coop;
 
 size_t pn2_mlp_workspace_bytes(int rows, const pn2_mlp_layer *layers, int nlayers, int nseg);

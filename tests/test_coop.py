@@ -52,7 +52,7 @@ def _run(x, layers, pool_k, first_col, coop):
         bn.running_mean.zero_()
         bn.running_var.fill_(1.0)
     xin = x.clone().requires_grad_(True)
-    with env(**({} if coop else {"PN2_NO_COOP": 1})):
+    with env(**({"PN2_COOP_MAX_ROWS": 100000} if coop else {"PN2_NO_COOP": 1})):   # (every shape here, whatever the default limit)
         y = mlp.chain_rows(xin, layers, pool_k=pool_k, dx_first_col=first_col)
         w = torch.cos(torch.arange(y.numel(), device="cuda", dtype=torch.float32) * 0.37).view_as(y)
         (y * w).sum().backward()
@@ -140,7 +140,7 @@ def test_whole_model_with_and_without_cooperative_chains():
              "semantic_labels": torch.zeros(n, dtype=torch.long, device="cuda"), "offset_labels": dev(off),
              "masks_off": torch.ones(n, dtype=torch.bool, device="cuda"), "masks_pad": torch.ones(1, n, dtype=torch.bool, device="cuda")}
     res = {}
-    for mode, e in (("coop", {}), ("plain", {"PN2_NO_COOP": 1})):
+    for mode, e in (("coop", {"PN2_COOP_MAX_ROWS": 10000}), ("plain", {"PN2_NO_COOP": 1})):
         torch.manual_seed(0)
         model = PointNet2(depth=4).cuda().train()
         torch.manual_seed(1)
