@@ -11,6 +11,9 @@
 namespace {
 
 constexpr int BK = 16, NT = 256;
+#ifndef PN2_DGRAD_OCC
+#define PN2_DGRAD_OCC 3
+#endif
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
@@ -531,7 +534,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g0, const TAB& st, con
 // One tile per workgroup: the launch grid is the tile grid.
 template <bool A_T, int A_KIND, bool B_T, int B_KIND, int EPI, int TILE, bool VEC, int TEAMS, bool BF16 = false, bool ACC = false,
           int NTT = NT>
-__global__ __launch_bounds__(NTT * TEAMS, (NTT == 64 ? 4 : TEAMS > 1 ? 1 : (EPI == EPI_STORE ? 2 : 3))) void gemm_kernel(const GemmArgs g0,
+__global__ __launch_bounds__(NTT * TEAMS, (NTT == 64 ? 4 : TEAMS > 1 ? 1 : (EPI == EPI_STORE ? PN2_DGRAD_OCC : 3))) void gemm_kernel(const GemmArgs g0,
                                                                                                                         const SegTable st) {
     __shared__ __attribute__((aligned(16))) float lds[TEAMS * 4 * BK * (TILE + 4)];
     gemm_body<A_T, A_KIND, B_T, B_KIND, EPI, TILE, VEC, TEAMS, BF16, ACC, false, NTT>(g0, st, (int)blockIdx.x, (int)blockIdx.y,
