@@ -12,7 +12,7 @@ namespace {
 
 constexpr int BK = 16, NT = 256;
 #ifndef PN2_DGRAD_OCC
-#define PN2_DGRAD_OCC 3
+#define PN2_DGRAD_OCC 2
 #endif
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
