@@ -397,6 +397,27 @@ size_t pn2_mlp_link_partial_bytes(int rows, int cin, int nseg, int32_t *block_ro
 int pn2_mlp_reduce_wgrad(const pn2_wgrad_task *tasks, int n, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * PointTransformerV3 serialized patch attention   replaces Modules/PointTransformerV3/blocks.py:384-437 and :457-488
+ *
+ * pn2_ptv3_pad_unpad_i64 -- get_padding_and_inverse (:384-437).  Clouds of n_i points are padded to whole patches of
+ *   patch_size (clouds not longer than one patch are left alone); off / offpad: device [B + 1] prefix sums of n_i and of the
+ *   padded sizes, cu_off: device [B + 1] prefix counts of patches per cloud (the caller has the cloud sizes on the host --
+ *   the reference indexes `offset` on the host as well).  Outputs (device): pad [n_pad] int64 = for every padded position the
+ *   serialized position it reads (the tail of a cloud's last patch repeats the positions one patch earlier, :409-420),
+ *   unpad [n] int64 = padded position of every serialized position, cu_seqlens [patches + 1] int32.
+ *
+ * pn2_ptv3_patch_attention_f32 -- the non-flash branch of SerializedAttention.forward (:457-488):
+ *   qkv rows [3][heads][head_dim] (row stride ld); order [n_rows] int64 = row of qkv behind every padded position (the
+ *   reference's `qkv[order]` gather, fused) or NULL; every patch_size consecutive positions form a patch;
+ *   out [n_rows][heads * head_dim] = softmax((q * scale) k^T) v per patch and head -- the K x K scores are never written.
+ *   head_dim must be 16 (every stage of the repository's configuration), patch_size <= 1024, n_rows % patch_size == 0.
+ *   precision: PN2_PRECISION_F32 (exact fp32 MFMA) or PN2_PRECISION_BF16 (bfloat16 operands, fp32 accumulation and softmax). */
+int pn2_ptv3_pad_unpad_i64(const int64_t *off, const int64_t *offpad, const int64_t *cu_off, int B, int patch_size, int64_t n_pad,
+                           int64_t *pad, int64_t *unpad, int32_t *cu_seqlens, void *stream);
+int pn2_ptv3_patch_attention_f32(const float *qkv, int64_t ld, const int64_t *order, int64_t n_rows, int patch_size, int heads,
+                                 int head_dim, float scale, float *out, int precision, void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * Closest-cylinder projection       replaces Modules/Projection.py:19-114 (closest_cylinder_cuda_batch; duplicated at
  *                                   PreProcessing/LabelGenerationCuda.py:20-110)
  *   points [N] rows of point_stride floats (xyz first); cylinders: start [M,3], axis_unit [M,3], axis_length [M],
