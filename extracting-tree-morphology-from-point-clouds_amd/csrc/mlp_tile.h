@@ -126,7 +126,11 @@ __device__ __forceinline__ float ld_coh(const float* p) { return __hip_atomic_lo
 // [k][outer]) tile: TILE/32 float4 per thread (+ as many for the second source) and the BatchNorm coefficients
 // of the thread's 4 channels in registers.  The channel is always the contiguous global index: k for the T
 // layout (reloaded per K-tile), the outer index for the D layout (loaded once).
-template <bool T_LAYOUT, int KIND, int TILE, bool VEC, int THREADS = NT, bool COH = false>
+// IMG16: the LDS image is bfloat16, [outer][k] with a row pitch of 48 bytes (16 values + 16 bytes of padding): the matrix-core
+// operand of v_mfma_f32_32x32x16_bf16 -- row r, eight consecutive k -- is then ONE conflict-free 16-byte read instead of eight
+// 4-byte reads and eight conversions out of the fp32 [k][outer] image (which made the bf16 mode LDS-bound).
+constexpr int kPitch16 = 48;
+template <bool T_LAYOUT, int KIND, int TILE, bool VEC, int THREADS = NT, bool COH = false, bool IMG16 = false>
 struct Stager {
     static constexpr int NP = TILE * BK / (4 * THREADS);   // 16-byte loads per thread per K-tile
     static constexpr int KT = BK / 4;        // T layout: threads along k per row
@@ -215,7 +219,18 @@ struct Stager {
             const bool in = r < o.rows && c + j < o.cols;
             w[j] = in ? xf(e[j], KIND == TR_DY ? yy[j] : 0.0f, j, o.relu) : 0.0f;
         }
-        if (T_LAYOUT) {
+        if (IMG16) {
+            char* S16 = (char*)S;
+            if (T_LAYOUT) {   // four consecutive k of one row: one 8-byte store
+                const int m = RPP * p + (tid / KT), k = 4 * (tid % KT);
+                using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+                *(bf16x4*)(S16 + m * kPitch16 + 2 * k) = bf16x4{(__bf16)w[0], (__bf16)w[1], (__bf16)w[2], (__bf16)w[3]};
+            } else {          // one k of four consecutive rows
+                const int k = KPP * p + (tid / OQ), m = 4 * (tid % OQ);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) *(__bf16*)(S16 + (m + j) * kPitch16 + 2 * k) = (__bf16)w[j];
+            }
+        } else if (T_LAYOUT) {
             const int m = RPP * p + (tid / KT), k = 4 * (tid % KT);
 #pragma unroll
             for (int j = 0; j < 4; ++j) S[(k + j) * LD + m] = w[j];
@@ -382,6 +397,7 @@ template <bool A_T, int A_KIND, bool B_T, int B_KIND, int EPI, int TILE, bool VE
 __device__ __forceinline__ void gemm_body(const GemmArgs& g0, const TAB& st, const int BX, const int BY, const int BZ,
                                           float* __restrict__ lds) {
     static_assert(NTT == NT || (NTT == 64 && TILE == 32 && TEAMS > 1), "single-wavefront teams are for the 32-tile");
+    static_assert(!BF16 || TILE * kPitch16 <= BK * (TILE + 4) * 4, "the bfloat16 image fits the fp32 image's buffer");
     constexpr int LD = TILE + 4, WT = NTT == 64 ? TILE : TILE / 2, NI = WT / 32;
     // Which rows does this workgroup own?  Row tiles (forward, dgrad) and reduction ranges (wgrad) never straddle a
     // segment: the operands' row limit, the output's row limit and the BatchNorm coefficient blocks are those of the
@@ -439,8 +455,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g0, const TAB& st, con
             }
     }
 
-    Stager<A_T, A_KIND, TILE, VEC, NTT, COH> sa;
-    Stager<B_T, B_KIND, TILE, VEC, NTT> sb;
+    Stager<A_T, A_KIND, TILE, VEC, NTT, COH, BF16> sa;
+    Stager<B_T, B_KIND, TILE, VEC, NTT, false, BF16> sb;
     sa.tid = tid;
     sb.tid = tid;
     sa.prepare(g.A, m0);
@@ -461,21 +477,24 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g0, const TAB& st, con
         }
         const float* a = As[cur] + wm * WT + l31;
         const float* b = Bs[cur] + wn * WT + l31;
+        (void)a;
+        (void)b;
         // The K-tile's MFMAs are issued in NP groups; after each group one pass of the NEXT tile is staged into the
         // other LDS buffer, so the staging VALU/LDS work sits in the shadow of the (asynchronous, 64-cycle) MFMAs
         // instead of forming a separate phase during which this wave's matrix pipe idles.
         constexpr int NP = TILE * BK / (4 * NTT), KQ = BK / NP;
         if constexpr (BF16) {
             static_assert(!BF16 || BK == 16, "one 32x32x16 MFMA consumes a whole K-tile");
-            // lane (r = lane & 31, h = lane >> 5) supplies A[row r][k = 8h + e] and B[k = 8h + e][col r], e = 0..7
+            // lane (r = lane & 31, h = lane >> 5) supplies A[row r][k = 8h + e] and B[k = 8h + e][col r], e = 0..7: eight
+            // consecutive values of row r of the bfloat16 image
             bf16x8 af[NI], bf[NI];
+            const char* a16 = (const char*)As[cur] + (wm * WT + l31) * kPitch16 + 16 * half;
+            const char* b16 = (const char*)Bs[cur] + (wn * WT + l31) * kPitch16 + 16 * half;
 #pragma unroll
-            for (int i = 0; i < NI; ++i)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    af[i][e] = (__bf16)a[(8 * half + e) * LD + 32 * i];
-                    bf[i][e] = (__bf16)b[(8 * half + e) * LD + 32 * i];
-                }
+            for (int i = 0; i < NI; ++i) {
+                af[i] = *(const bf16x8*)(a16 + 32 * i * kPitch16);
+                bf[i] = *(const bf16x8*)(b16 + 32 * i * kPitch16);
+            }
 #pragma unroll
             for (int i = 0; i < NI; ++i)
 #pragma unroll
