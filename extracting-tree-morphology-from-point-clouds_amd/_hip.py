@@ -119,6 +119,7 @@ SIGNATURES = {
     "pn2_prof_collect": (_int, [ctypes.c_char_p, _sz, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong),
                                 ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _int]),
     "pn2_mlp_workspace_bytes": (_sz, [_int, _lp, _int, _int]),
+    "pn2_mlp_chain_bf16_storage": (_int, [_int, _lp, _int, _int]),
     "pn2_mlp_chain_fwd_f32": (_int, [_vp, _i64, _int, _lp, _int, _int, _int, _vp, _vp, _sp, _int, _cp, _vp, _sz, _vp]),
     "pn2_mlp_link_partial_bytes": (_sz, [_int, _int, _int, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "pn2_mlp_reduce_wgrad": (_int, [ctypes.POINTER(WgradTask), _int, _vp]),
@@ -145,6 +146,7 @@ ABI_VERSION = 4                      # PN2_ABI_VERSION of include/pn2_hip.h
 CHAIN_ACCUMULATE_DX = 0x100          # PN2_CHAIN_ACCUMULATE_DX
 CHAIN_LAZY_OUT = 0x400               # PN2_CHAIN_LAZY_OUT
 CHAIN_ZERO_LEAD = 0x800              # PN2_CHAIN_ZERO_LEAD
+CHAIN_X_BF16, CHAIN_STORE_BF16, CHAIN_DOUT_BF16, CHAIN_DX_BF16 = 0x1000, 0x2000, 0x4000, 0x8000   # PN2_CHAIN_*_BF16
 STATUS_FPS_HANDOFF, STATUS_FPS_ARRIVAL, STATUS_BAD_INDEX, STATUS_COOP_BARRIER = 1, 2, 4, 8   # PN2_STATUS_* bits
 
 

@@ -283,7 +283,7 @@ struct FwdArgs {
 
 template <int A_KIND, bool VEC>
 __device__ __forceinline__ void fwd_tile(const GemmArgs& g, const OneSeg& st, int bx, int by, float* lds) {
-    gemm_body<true, A_KIND, true, TR_PLAIN, EPI_FWD, TL, VEC, 4, false, false, true, NTT>(g, st, bx, by, 0, lds);
+    gemm_body<true, A_KIND, true, TR_PLAIN, EPI_FWD, TL, VEC, 4, false, false, true, NTT, 0>(g, st, bx, by, 0, lds);
 }
 
 // (The argument block is read through the kernarg segment pointer: a by-value struct indexed with a run-time layer number
@@ -452,11 +452,11 @@ struct BwdArgs {
 
 template <bool VEC>
 __device__ __forceinline__ void dgrad_tile(const GemmArgs& g, const OneSeg& st, int bx, int by, float* lds) {
-    gemm_body<true, TR_DY, false, TR_PLAIN, EPI_STORE, TL, VEC, 4, false, false, true, NTT>(g, st, bx, by, 0, lds);
+    gemm_body<true, TR_DY, false, TR_PLAIN, EPI_STORE, TL, VEC, 4, false, false, true, NTT, 0>(g, st, bx, by, 0, lds);
 }
 template <int B_KIND, bool VEC>
 __device__ __forceinline__ void wgrad_tile(const GemmArgs& g, const OneSeg& st, int bx, int by, int bz, float* lds) {
-    gemm_body<false, TR_DY, false, B_KIND, EPI_SLAB, TL, VEC, 4, false, false, true, NTT>(g, st, bx, by, bz, lds);
+    gemm_body<false, TR_DY, false, B_KIND, EPI_SLAB, TL, VEC, 4, false, false, true, NTT, 0>(g, st, bx, by, bz, lds);
 }
 
 __global__ __launch_bounds__(CT, 2) void chain_coop_bwd_kernel(const BwdArgs) {

@@ -419,14 +419,14 @@ __global__ void bn_eval_coef_kernel(int C, const float* __restrict__ gamma, cons
 constexpr int APPLY_R = 64;
 __global__ __launch_bounds__(256) void bn_relu_apply_seg_kernel(const float* __restrict__ y, const SegTable st, int C,
                                                                 const float* __restrict__ coef, int relu,
-                                                                float* __restrict__ z) {
+                                                                float* __restrict__ z, int y16) {
     const RowBlock rb = row_block(st, (int)blockIdx.x, APPLY_R);
     const int r1 = rb.row0 + APPLY_R < rb.row_end ? rb.row0 + APPLY_R : rb.row_end;
     const float* cf = coef + (long long)rb.seg * ST_ROWS * C;
     const long long e0 = (long long)rb.row0 * C / 4, e1 = (long long)r1 * C / 4;
     for (long long e = e0 + threadIdx.x; e < e1; e += 256) {
         const int c = (int)((e * 4) % C);
-        const float4 v = ((const float4*)y)[e];
+        const float4 v = ld_row4(y, e * 4, y16 != 0);
         const float4 mean = *(const float4*)(cf + ST_MEAN * C + c);
         const float4 sc = *(const float4*)(cf + ST_SCALE * C + c);
         const float4 bt = *(const float4*)(cf + ST_BETA * C + c);
@@ -446,10 +446,10 @@ __global__ __launch_bounds__(256) void bn_relu_apply_seg_kernel(const float* __r
 }
 
 __global__ __launch_bounds__(256) void bn_relu_apply_kernel(const float* __restrict__ y, long long total4, int C,
-                                                            const float* __restrict__ coef, int relu, float* __restrict__ z) {
+                                                            const float* __restrict__ coef, int relu, float* __restrict__ z, int y16) {
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total4; e += (long long)gridDim.x * 256) {
         const int c = (int)((e * 4) % C);
-        const float4 v = ((const float4*)y)[e];
+        const float4 v = ld_row4(y, e * 4, y16 != 0);
         const float4 mean = *(const float4*)(coef + ST_MEAN * C + c);
         const float4 sc = *(const float4*)(coef + ST_SCALE * C + c);
         const float4 bt = *(const float4*)(coef + ST_BETA * C + c);
@@ -582,7 +582,7 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dz, long long lddz,
                                                             const float* __restrict__ y, long long ldy, int rows, int C,
                                                             const float* __restrict__ coef, int relu,
-                                                            float* __restrict__ partial, const SegTable st) {
+                                                            float* __restrict__ partial, const SegTable st, int dz16, int y16) {
     __shared__ float red[2][256][4];
     const RowBlock rb = row_block(st, (int)blockIdx.x, RB);
     const int r0 = rb.row0;
@@ -610,8 +610,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int r = rr + u * rg < r1 ? rr + u * rg : r1 - 1;
-                    yv[u] = ld4<VEC>(y, ldy, r, c, rows, C);
-                    dv[u] = ld4<VEC>(dz, lddz, r, c, rows, C);
+                    yv[u] = y16 ? ld4h<VEC>(y, ldy, r, c, rows, C) : ld4<VEC>(y, ldy, r, c, rows, C);      // (bfloat16 storage: uniform)
+                    dv[u] = dz16 ? ld4h<VEC>(dz, lddz, r, c, rows, C) : ld4<VEC>(dz, lddz, r, c, rows, C);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -790,7 +790,7 @@ __device__ __forceinline__ float group_sum(float v) {
     return v;
 }
 
-template <int KL, bool HAS_BN>
+template <int KL, bool HAS_BN, bool Y16 = false>
 __global__ __launch_bounds__(NR_T) void narrow_fwd_kernel(const float* __restrict__ y, long long ldy, int rows, int K,
                                                          const float* __restrict__ coef, int relu,
                                                          const float* __restrict__ W, const float* __restrict__ bias, int N,
@@ -823,7 +823,7 @@ __global__ __launch_bounds__(NR_T) void narrow_fwd_kernel(const float* __restric
         for (int u = 0; u < UF; ++u) {
             rbu[u] = r0 + (it0 + u) * RGF + wave * RPW + rsub;
             const int r = rbu[u] < r1 ? rbu[u] : r1 - 1;
-            v[u] = *(const float4*)(y + (long long)r * ldy + k);
+            v[u] = ld_row4(y, (long long)r * ldy + k, Y16);
         }
 #pragma unroll
         for (int u = 0; u < UF; ++u) {   // steps beyond iters compute on the last row and store nothing
@@ -848,7 +848,7 @@ __global__ __launch_bounds__(NR_T) void narrow_fwd_kernel(const float* __restric
     }
 }
 
-template <int KL, bool HAS_BN>
+template <int KL, bool HAS_BN, bool Y16 = false, bool DX16 = false>
 __global__ __launch_bounds__(NR_T) void narrow_bwd_kernel(const float* __restrict__ dout, int rows, int K, int N,
                                                          const float* __restrict__ y, long long ldy,
                                                          const float* __restrict__ coef, int relu,
@@ -882,7 +882,7 @@ __global__ __launch_bounds__(NR_T) void narrow_bwd_kernel(const float* __restric
     const int r0 = rb.row0;
     const int r1 = r0 + NR_ROWS < rb.row_end ? r0 + NR_ROWS : rb.row_end;
     for (int r = r0 + rgp; r < r1; r += RG) {
-        const float4 v = *(const float4*)(y + (long long)r * ldy + k);
+        const float4 v = ld_row4(y, (long long)r * ldy + k, Y16);
         const float e[4] = {v.x, v.y, v.z, v.w};
         float g[NMAX];
 #pragma unroll
@@ -908,7 +908,7 @@ __global__ __launch_bounds__(NR_T) void narrow_bwd_kernel(const float* __restric
                 s2[j] += dzh * ((e[j] - cm[j]) * ci[j]);
             }
         }
-        *(float4*)(dx + (long long)r * K + k) = make_float4(o[0], o[1], o[2], o[3]);
+        st_row4(dx, (long long)r * K + k, make_float4(o[0], o[1], o[2], o[3]), DX16);
         if (kq == 0)
 #pragma unroll
             for (int n = 0; n < NMAX; ++n) db[n] += g[n];
@@ -1042,7 +1042,7 @@ inline int pick_tile(int M, int N, int nsplit) {
 
 // Row-tiled roles (forward, dgrad): grid.x = row tiles of the segments; wgrad: grid.z = reduction ranges of the segments
 // (`g.k_per_split` rows each), grid.x tiles the output rows (= cout).
-template <bool A_T, int A_KIND, bool B_T, int B_KIND, int EPI, int TILE, bool VEC, int TEAMS = 1, bool BF16 = false, int NTT = NT>
+template <bool A_T, int A_KIND, bool B_T, int B_KIND, int EPI, int TILE, bool VEC, int TEAMS = 1, bool BF16 = false, int NTT = NT, int ST = 0>
 int launch_gemm_tv(GemmArgs& g, const Segs& S, hipStream_t s, int* nblk_out) {
     int nblk = 0;
     const SegTable st = make_table(S, EPI == EPI_SLAB ? g.k_per_split : TILE, &nblk);
@@ -1060,10 +1060,10 @@ int launch_gemm_tv(GemmArgs& g, const Segs& S, hipStream_t s, int* nblk_out) {
     const double bytes = 4.0 * (mk + kn + (double)g.M * g.N * ((EPI == EPI_SLAB ? nblk : 1) + extra));
     if (closing)
         PN2_LAUNCH(name, bytes, 2.0 * g.M * g.N * g.K,
-                   (gemm_kernel<A_T, A_KIND, B_T, B_KIND, EPI, TILE, VEC, TEAMS, BF16, EPI == EPI_STORE, NTT>), grid, dim3(NTT * TEAMS), s, g,
+                   (gemm_kernel<A_T, A_KIND, B_T, B_KIND, EPI, TILE, VEC, TEAMS, BF16, EPI == EPI_STORE, NTT, ST>), grid, dim3(NTT * TEAMS), s, g,
                    st);
     else
-        PN2_LAUNCH(name, bytes, 2.0 * g.M * g.N * g.K, (gemm_kernel<A_T, A_KIND, B_T, B_KIND, EPI, TILE, VEC, TEAMS, BF16, false, NTT>),
+        PN2_LAUNCH(name, bytes, 2.0 * g.M * g.N * g.K, (gemm_kernel<A_T, A_KIND, B_T, B_KIND, EPI, TILE, VEC, TEAMS, BF16, false, NTT, ST>),
                    grid, dim3(NTT * TEAMS), s, g, st);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
@@ -1074,6 +1074,23 @@ inline long long grid_blocks(int M, int N, int tile) { return (long long)pn2::ce
 template <bool A_T, int A_KIND, bool B_T, int B_KIND, int EPI>
 int launch_gemm(GemmArgs& g, const Segs& S, int tile, hipStream_t s, int* nblk_out = nullptr) {
     const bool vec = vec_ok(g.A) && vec_ok(g.B);
+    const int st16 = (g.A.p16 ? 1 : 0) | (g.B.p16 ? 2 : 0) | (g.c16 ? 4 : 0) | (g.ey16 ? 8 : 0);
+    if (st16 && !(tile == 128 && g.precision == PN2_PRECISION_BF16 && vec)) return PN2_E_BADARG;   // bfloat16 rows: these kernels only
+    if (st16) {
+        // the storage layouts the chains produce (pn2_hip.h PN2_CHAIN_STORE_BF16), each a kernel of its own: the row type is a
+        // compile-time property (a run-time branch between a K-tile's loads serialises their round trips)
+        if (g.A.q && g.A.p16 != g.A.q16) return PN2_E_BADARG;
+#define PN2_ST_CASE(V) case V: return launch_gemm_tv<A_T, A_KIND, B_T, B_KIND, EPI, 128, true, 1, true, NT, V>(g, S, s, nblk_out)
+        if constexpr (EPI == EPI_FWD) {
+            switch (st16) { PN2_ST_CASE(4); PN2_ST_CASE(5); default: return PN2_E_BADARG; }
+        } else if constexpr (EPI == EPI_STORE) {
+            if (g.partial && !g.ey16) return PN2_E_BADARG;   // (a bfloat16 chain is linked to bfloat16 rows only)
+            switch (st16 | 8) { PN2_ST_CASE(9); PN2_ST_CASE(13); default: return PN2_E_BADARG; }
+        } else {
+            switch (st16) { PN2_ST_CASE(1); PN2_ST_CASE(3); default: return PN2_E_BADARG; }
+        }
+#undef PN2_ST_CASE
+    }
     if (tile == 128 && g.precision == PN2_PRECISION_BF16 && vec)   // the small-problem tiles always run fp32
         return launch_gemm_tv<A_T, A_KIND, B_T, B_KIND, EPI, 128, true, 1, true>(g, S, s, nblk_out);
     if (tile == 128)
@@ -1102,7 +1119,12 @@ int launch_narrow_fwd_kl(const Act& in, int rows, const pn2_mlp_layer& L, float*
     const SegTable st = make_table(S, NR_ROWS, &nblk);
     const dim3 grid(nblk), block(NR_T);
     const double bytes = 4.0 * rows * (L.cin + L.cout), flops = 2.0 * rows * L.cin * L.cout;
-    if (in.coef)
+    if (in.coef && in.h16)
+        PN2_LAUNCH("narrow_fwd", bytes * 0.5, flops, (narrow_fwd_kernel<KL, true, true>), grid, block, s, in.p, in.ld, rows, L.cin, in.coef,
+                   in.relu, L.weight, L.bias, L.cout, out, st);
+    else if (in.h16)
+        return PN2_E_BADARG;
+    else if (in.coef)
         PN2_LAUNCH("narrow_fwd", bytes, flops, (narrow_fwd_kernel<KL, true>), grid, block, s, in.p, in.ld, rows, L.cin, in.coef,
                    in.relu, L.weight, L.bias, L.cout, out, st);
     else
@@ -1118,10 +1140,14 @@ int launch_narrow_fwd(const Act& in, int rows, const pn2_mlp_layer& L, float* ou
 
 template <int KL>
 int launch_narrow_bwd_kl(const Act& in, int rows, const pn2_mlp_layer& L, const float* dout, float* dx, float* part_s,
-                         float* part_w, float* part_b, const SegTable& st, int nblk, hipStream_t s) {
+                         float* part_w, float* part_b, const SegTable& st, int nblk, hipStream_t s, int dx16) {
     const dim3 grid(nblk), block(NR_T);
     const double bytes = 4.0 * rows * (2.0 * L.cin + L.cout), flops = 4.0 * rows * L.cin * L.cout;
-    if (in.coef)
+    if (in.h16 != dx16 || (in.h16 && !in.coef)) return PN2_E_BADARG;   // bfloat16 storage: rows in and gradient rows out together
+    if (in.h16)
+        PN2_LAUNCH("narrow_bwd", bytes * 0.5, flops, (narrow_bwd_kernel<KL, true, true, true>), grid, block, s, dout, rows, L.cin, L.cout,
+                   in.p, in.ld, in.coef, in.relu, L.weight, dx, part_s, part_w, part_b, st);
+    else if (in.coef)
         PN2_LAUNCH("narrow_bwd", bytes, flops, (narrow_bwd_kernel<KL, true>), grid, block, s, dout, rows, L.cin, L.cout, in.p, in.ld,
                    in.coef, in.relu, L.weight, dx, part_s, part_w, part_b, st);
     else
@@ -1131,10 +1157,10 @@ int launch_narrow_bwd_kl(const Act& in, int rows, const pn2_mlp_layer& L, const 
     return e == hipSuccess ? 0 : (int)e;
 }
 int launch_narrow_bwd(const Act& in, int rows, const pn2_mlp_layer& L, const float* dout, float* dx, float* part_s,
-                      float* part_w, float* part_b, const SegTable& st, int nblk, hipStream_t s) {
-    return L.cin == 64 ? launch_narrow_bwd_kl<16>(in, rows, L, dout, dx, part_s, part_w, part_b, st, nblk, s)
-           : L.cin == 128 ? launch_narrow_bwd_kl<32>(in, rows, L, dout, dx, part_s, part_w, part_b, st, nblk, s)
-                          : launch_narrow_bwd_kl<64>(in, rows, L, dout, dx, part_s, part_w, part_b, st, nblk, s);
+                      float* part_w, float* part_b, const SegTable& st, int nblk, hipStream_t s, int dx16) {
+    return L.cin == 64 ? launch_narrow_bwd_kl<16>(in, rows, L, dout, dx, part_s, part_w, part_b, st, nblk, s, dx16)
+           : L.cin == 128 ? launch_narrow_bwd_kl<32>(in, rows, L, dout, dx, part_s, part_w, part_b, st, nblk, s, dx16)
+                          : launch_narrow_bwd_kl<64>(in, rows, L, dout, dx, part_s, part_w, part_b, st, nblk, s, dx16);
 }
 
 struct WgradPlan {
@@ -1267,6 +1293,20 @@ inline long long cm_stride(int rows, int tile, int nseg) {
 // row-block size of the dgrad that produces a linked chain's input gradient (two partial chunks per block)
 inline int link_tile(int rows, int cin) { return pick_tile(rows, cin, 1); }
 
+// bf16 mode with bfloat16 STORAGE of the chain's pre-BatchNorm rows and gradient rows: every contraction of the chain must be one of
+// the 128-tile, 16-byte-staged kernels (the only ones with the bfloat16 load / store paths), no pooling.
+bool chain_bf16_storage_ok(int rows, const pn2_mlp_layer* layers, int nlayers, int pool_k) {
+    if (pool_k > 1 || rows <= 0 || nlayers <= 0) return false;
+    for (int i = 0; i < nlayers; ++i) {
+        const pn2_mlp_layer& L = layers[i];
+        const bool last = i == nlayers - 1;
+        if (narrow_ok(L, last, pool_k)) continue;
+        if (!L.has_bn || L.cin % 4 || L.cout % 4) return false;
+        if (pick_tile(rows, L.cout, 1) != 128 || pick_tile(rows, L.cin, 1) != 128) return false;
+    }
+    return true;
+}
+
 // cooperative launches: asked for by the caller (a sync buffer) and not switched off (PN2_NO_COOP: A/B and test aid)
 inline bool coop_usable(const pn2_coop* c) {
     return c && c->sync && !getenv("PN2_NO_COOP");
@@ -1308,6 +1348,10 @@ size_t partial_region_bytes(int rows, const pn2_mlp_layer* layers, int nlayers, 
 }
 }  // namespace
 
+extern "C" int pn2_mlp_chain_bf16_storage(int rows, const pn2_mlp_layer* layers, int nlayers, int pool_k) {
+    return layers && chain_bf16_storage_ok(rows, layers, nlayers, pool_k) ? 1 : 0;
+}
+
 extern "C" size_t pn2_mlp_workspace_bytes(int rows, const pn2_mlp_layer* layers, int nlayers, int nseg) {
     if (rows <= 0 || !layers || nlayers <= 0) return 0;
     if (nseg < 1) nseg = 1;
@@ -1333,7 +1377,10 @@ extern "C" int pn2_mlp_chain_fwd_f32(const float* x, int64_t ldx, int rows, cons
                                      int training, int pool_k, float* out, int32_t* pool_arg, const pn2_segments* segments,
                                      int precision, const pn2_coop* coop, void* workspace, size_t workspace_bytes, void* stream) {
     const bool lazy_out = (precision & PN2_CHAIN_LAZY_OUT) != 0;
-    precision &= ~PN2_CHAIN_LAZY_OUT;
+    const int x16 = (precision & PN2_CHAIN_X_BF16) ? 1 : 0, s16 = (precision & PN2_CHAIN_STORE_BF16) ? 1 : 0;
+    precision &= ~(PN2_CHAIN_LAZY_OUT | PN2_CHAIN_X_BF16 | PN2_CHAIN_STORE_BF16);
+    if ((x16 || s16) && (precision != PN2_PRECISION_BF16 || !s16 || !chain_bf16_storage_ok(rows, layers, nlayers, pool_k)))
+        return PN2_E_BADARG;
     if (!x || !layers || nlayers <= 0 || rows <= 0 || (!out && !lazy_out) || (pool_k > 1 && (!pool_arg || rows % pool_k)))
         return PN2_E_BADARG;
     if (lazy_out && (pool_k > 1 || !layers[nlayers - 1].has_bn)) return PN2_E_BADARG;
@@ -1354,7 +1401,8 @@ extern "C" int pn2_mlp_chain_fwd_f32(const float* x, int64_t ldx, int rows, cons
         c.ctl = coop, c.stream = s;
         return pn2::coop::forward(c);
     }
-    Act in{x, ldx, layers[0].in_stats, layers[0].in_stats ? layers[0].in_relu : 0};   // linked chain: BN(+ReLU) while staging
+    if (x16 && !layers[0].in_stats) return PN2_E_BADARG;   // bfloat16 input rows only exist as a linked producer's rows
+    Act in{x, ldx, layers[0].in_stats, layers[0].in_stats ? layers[0].in_relu : 0, x16};   // linked chain: BN(+ReLU) while staging
     for (int i = 0; i < nlayers; ++i) {
         const pn2_mlp_layer& L = layers[i];
         if (!L.weight || L.cin <= 0 || L.cout <= 0) return PN2_E_BADARG;
@@ -1371,6 +1419,7 @@ extern "C" int pn2_mlp_chain_fwd_f32(const float* x, int64_t ldx, int rows, cons
         g.K = L.cin;
         g.C = y;
         g.ldc = L.cout;
+        g.c16 = (s16 && !direct_out) ? 1 : 0;
         g.bias = L.bias;
         g.partial = (L.has_bn && training) ? (float*)workspace : nullptr;
         const int tile = pick_tile(rows, L.cout, 1);
@@ -1392,10 +1441,10 @@ extern "C" int pn2_mlp_chain_fwd_f32(const float* x, int64_t ldx, int rows, cons
                            L.cout, L.gamma, L.beta, L.running_mean, L.running_var, L.eps, L.stats);
                 PN2_LAUNCH_CHECK();
             }
-            in = Act{y, L.cout, L.stats, L.relu};
+            in = Act{y, L.cout, L.stats, L.relu, s16};
         } else {
             if (L.relu && !last) return PN2_E_BADARG;  // ReLU without BatchNorm only exists fused into a BN layer here
-            in = Act{y, L.cout, nullptr, 0};
+            in = Act{y, L.cout, nullptr, 0, 0};
         }
         if (last && !direct_out && !lazy_out) {
             const int C = L.cout;
@@ -1410,10 +1459,10 @@ extern "C" int pn2_mlp_chain_fwd_f32(const float* x, int64_t ldx, int rows, cons
             } else if (S.nseg > 1) {
                 const SegTable tb = make_table(S, APPLY_R, &nblk);
                 PN2_LAUNCH("bn_relu_apply", 8.0 * rows * C, 0, bn_relu_apply_seg_kernel, dim3(nblk), dim3(256), s, (const float*)y, tb,
-                           C, (const float*)L.stats, L.relu, out);
+                           C, (const float*)L.stats, L.relu, out, s16);
             } else {
                 PN2_LAUNCH("bn_relu_apply", 8.0 * rows * C, 0, bn_relu_apply_kernel, dim3(grid1d((long long)rows * C / 4)),
-                           dim3(256), s, (const float*)y, (long long)rows * C / 4, C, (const float*)L.stats, L.relu, out);
+                           dim3(256), s, (const float*)y, (long long)rows * C / 4, C, (const float*)L.stats, L.relu, out, s16);
             }
             PN2_LAUNCH_CHECK();
         }
@@ -1433,7 +1482,15 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
     const bool defer_wgrad = deferred && deferred->n >= 0 && deferred->n + nlayers <= PN2_WGRAD_TASKS_MAX;
     bool zero_lead = (precision & PN2_CHAIN_ZERO_LEAD) != 0 && dx && dx_first_col > 0;
     if (zero_lead && accumulate_dx) return PN2_E_BADARG;
-    precision &= ~(PN2_CHAIN_ACCUMULATE_DX | PN2_CHAIN_ZERO_LEAD);
+    // bfloat16 storage (pn2_hip.h): which of the row tensors of this call are __bf16
+    const int x16 = (precision & PN2_CHAIN_X_BF16) ? 1 : 0, s16 = (precision & PN2_CHAIN_STORE_BF16) ? 1 : 0;
+    const int dout16 = (precision & PN2_CHAIN_DOUT_BF16) ? 1 : 0, dx16 = (precision & PN2_CHAIN_DX_BF16) ? 1 : 0;
+    precision &= ~(PN2_CHAIN_ACCUMULATE_DX | PN2_CHAIN_ZERO_LEAD | PN2_CHAIN_X_BF16 | PN2_CHAIN_STORE_BF16 | PN2_CHAIN_DOUT_BF16 |
+                   PN2_CHAIN_DX_BF16);
+    if ((x16 || s16 || dout16 || dx16) &&
+        (precision != PN2_PRECISION_BF16 || !s16 || dx_first_col || !chain_bf16_storage_ok(rows, layers, nlayers, pool_k)))
+        return PN2_E_BADARG;
+    if (x16 && !layers[0].in_stats) return PN2_E_BADARG;
     if (precision != PN2_PRECISION_F32 && precision != PN2_PRECISION_BF16) return PN2_E_BADARG;
     if (accumulate_dx && !dx) return PN2_E_BADARG;
     if (!segs_valid(rows, segments, pool_k)) return PN2_E_BADARG;
@@ -1490,6 +1547,7 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
     }
     // dz of the last layer: upstream gradient, or the max-pool scatter of it
     const float* dz = dout;
+    int dz16 = dout16;
     long long lddz = layers[nlayers - 1].cout;
     float* bufs[2] = {scratch_a, scratch_b};
     int which = 0;
@@ -1554,10 +1612,10 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
                 const bool vec = (L.cout % 4 == 0) && (lddz % 4 == 0) && aligned16(dz) && aligned16(y);
                 if (vec)
                     PN2_LAUNCH("bn_bwd_reduce", 8.0 * rows * L.cout, 0, (bn_bwd_reduce_kernel<true>), dim3(nblk), dim3(256), s, dz,
-                               lddz, y, (long long)L.cout, rows, L.cout, (const float*)L.stats, L.relu, ws, tb);
+                               lddz, y, (long long)L.cout, rows, L.cout, (const float*)L.stats, L.relu, ws, tb, dz16, s16);
                 else
                     PN2_LAUNCH("bn_bwd_reduce", 8.0 * rows * L.cout, 0, (bn_bwd_reduce_kernel<false>), dim3(nblk), dim3(256), s, dz,
-                               lddz, y, (long long)L.cout, rows, L.cout, (const float*)L.stats, L.relu, ws, tb);
+                               lddz, y, (long long)L.cout, rows, L.cout, (const float*)L.stats, L.relu, ws, tb, dz16, s16);
                 PN2_LAUNCH_CHECK();
             }
             if ((st = launch_bn_bwd_finalize(partial, sp, S, R, cpb, rows, L, s, cm))) return st;
@@ -1571,9 +1629,9 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
         fused_R = fused_cpb = 0;
         fused_cm = 0;
         // layer input as an activation source
-        Act in = i == 0 ? Act{x, ldx, layers[0].in_stats, layers[0].in_stats ? layers[0].in_relu : 0}
+        Act in = i == 0 ? Act{x, ldx, layers[0].in_stats, layers[0].in_stats ? layers[0].in_relu : 0, x16}
                         : Act{layers[i - 1].y, layers[i - 1].cout, layers[i - 1].has_bn ? layers[i - 1].stats : nullptr,
-                              layers[i - 1].relu};
+                              layers[i - 1].relu, s16};
         // ---- narrow last layer: one vector-ALU pass does dgrad, wgrad, bias sums and the previous layer's BN sums
         if (narrow_ok(L, last, pool_k) && lddz == L.cout && in.ld % 4 == 0 && aligned16(in.p)) {
             int nblk = 0;
@@ -1583,7 +1641,9 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
             float* part_b = part_w + (size_t)nblk * L.cout * L.cin;
             float* target = i > 0 ? bufs[which] : (dx ? dx : bufs[which]);
             if (i == 0 && dx && (lddx != L.cin || accumulate_dx)) return PN2_E_BADARG;   // the narrow kernel stores
-            int st = launch_narrow_bwd(in, rows, L, dz, target, part_s, part_w, part_b, tb, nblk, s);
+            if (dz16) return PN2_E_BADARG;                                               // (its upstream gradient is fp32)
+            const int t16 = (i > 0 || !dx) ? s16 : dx16;
+            int st = launch_narrow_bwd(in, rows, L, dz, target, part_s, part_w, part_b, tb, nblk, s, t16);
             if (st) return st;
             if (L.dweight)
                 launch_slab_reduce((const float*)part_w, nblk, (long long)L.cout * L.cin, L.dweight, s);
@@ -1596,14 +1656,17 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
                 fused_cpb = 1;
             }
             dz = target;
+            dz16 = t16;
             lddz = L.cin;
             which ^= 1;
             continue;
         }
         // dY operand (through BatchNorm+ReLU backward when the layer has one)
         Operand dy = plain(dz, lddz, rows, L.cout);
+        dy.p16 = dz16;
         if (L.has_bn) {
             dy.q = y;
+            dy.q16 = s16;
             dy.ldq = L.cout;
             dy.coef = L.stats;
             dy.cstride = L.cout;
@@ -1658,6 +1721,8 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
             g.K = L.cout;
             g.C = target;
             g.ldc = ldt;
+            g.c16 = i > 0 ? s16 : dx16;
+            g.ey16 = i > 0 ? s16 : x16;
             g.accumulate = i == 0 ? accumulate_dx : 0;
             const int tile = pick_tile(rows, L.cin - skip, 1);
             if (i > 0 && layers[i - 1].has_bn) {
@@ -1682,6 +1747,7 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
                               : launch_gemm<true, TR_PLAIN, false, TR_PLAIN, EPI_STORE>(g, S, tile, s);
             if (st) return st;
             dz = target;
+            dz16 = i > 0 ? s16 : dx16;
             lddz = ldt;
             which ^= 1;
         }

@@ -70,6 +70,7 @@ struct Operand {
     const float* coef;  // coefficient block [ST_ROWS][cstride] of the BatchNorm involved, or null
     int cstride;
     int relu;
+    int p16, q16;       // bf16 mode with bfloat16 STORAGE: p / q point to __bf16 rows (ld / ldq still count elements)
 };
 
 // Branch-free tile loads: the address is clamped into the matrix and the value masked afterwards, so that all of
@@ -90,6 +91,42 @@ __device__ __forceinline__ float4 ld4(const float* base, long long ld, int r, in
     v.z = p[c + 2 < last ? c + 2 : last];
     v.w = p[c + 3 < last ? c + 3 : last];
     return v;
+}
+
+// The same load from rows stored as bfloat16 (bf16 mode, PN2_CHAIN_STORE_BF16): four values = 8 bytes, widened exactly.
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+template <bool VEC>
+__device__ __forceinline__ float4 ld4h(const float* base_, long long ld, int r, int c, int nrows, int ncols) {
+    const unsigned short* base = (const unsigned short*)base_;
+    const int rc = r < nrows ? r : nrows - 1;
+    if (VEC) {
+        const int cc = c < ncols ? c : ncols - 4;
+        const uint2 u = *(const uint2*)(base + (long long)rc * ld + cc);
+        return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16),
+                           __uint_as_float(u.y & 0xFFFF0000u));
+    }
+    const unsigned short* p = base + (long long)rc * ld;
+    const int last = ncols - 1;
+    return make_float4(bf16_to_f32(p[c < last ? c : last]), bf16_to_f32(p[c + 1 < last ? c + 1 : last]),
+                       bf16_to_f32(p[c + 2 < last ? c + 2 : last]), bf16_to_f32(p[c + 3 < last ? c + 3 : last]));
+}
+
+// Y16 / DX16: the activation rows read / the input-gradient rows written are bfloat16 (bf16 mode with bfloat16 storage)
+__device__ __forceinline__ float4 ld_row4(const float* base, long long elem, bool h16) {
+    if (h16) {
+        const uint2 u = *(const uint2*)((const unsigned short*)base + elem);
+        return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xFFFF0000u), __uint_as_float(u.y << 16),
+                           __uint_as_float(u.y & 0xFFFF0000u));
+    }
+    return *(const float4*)(base + elem);
+}
+__device__ __forceinline__ void st_row4(float* base, long long elem, float4 v, bool h16) {
+    if (h16) {
+        using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+        *(bf16x4*)((unsigned short*)base + elem) = bf16x4{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+    } else {
+        *(float4*)(base + elem) = v;
+    }
 }
 
 // COHERENT tile I/O for the cooperative chain kernels (chain_coop.hip part below): rows written by OTHER workgroups of
@@ -130,7 +167,11 @@ __device__ __forceinline__ float ld_coh(const float* p) { return __hip_atomic_lo
 // operand of v_mfma_f32_32x32x16_bf16 -- row r, eight consecutive k -- is then ONE conflict-free 16-byte read instead of eight
 // 4-byte reads and eight conversions out of the fp32 [k][outer] image (which made the bf16 mode LDS-bound).
 constexpr int kPitch16 = 48;
-template <bool T_LAYOUT, int KIND, int TILE, bool VEC, int THREADS = NT, bool COH = false, bool IMG16 = false>
+#ifndef PN2_PAIRED_STORE
+#define PN2_PAIRED_STORE 0
+#endif
+constexpr bool kPairedStore = PN2_PAIRED_STORE != 0;   // bfloat16 C as 4-byte column pairs (measured slower than 2-byte stores: off)
+template <bool T_LAYOUT, int KIND, int TILE, bool VEC, int THREADS = NT, bool COH = false, bool IMG16 = false, bool SRC16 = false>
 struct Stager {
     static constexpr int NP = TILE * BK / (4 * THREADS);   // 16-byte loads per thread per K-tile
     static constexpr int KT = BK / 4;        // T layout: threads along k per row
@@ -190,6 +231,10 @@ struct Stager {
             if (COH && KIND != TR_PLAIN) {   // dZ / Y rows another workgroup of this launch may have written
                 v[p] = ld4_coh<VEC>(o.p, o.ld, r, c, o.rows, o.cols);
                 if (KIND == TR_DY) y[p] = ld4_coh<VEC>(o.q, o.ldq, r, c, o.rows, o.cols);
+            } else if (SRC16) {   // bf16 mode, bfloat16 storage: both sources are __bf16 rows (compile-time: a branch between
+                                  // the loads of a K-tile would serialise their round trips)
+                v[p] = ld4h<VEC>(o.p, o.ld, r, c, o.rows, o.cols);
+                if (KIND == TR_DY) y[p] = ld4h<VEC>(o.q, o.ldq, r, c, o.rows, o.cols);
             } else {
                 v[p] = ld4<VEC>(o.p, o.ld, r, c, o.rows, o.cols);
                 if (KIND == TR_DY) y[p] = ld4<VEC>(o.q, o.ldq, r, c, o.rows, o.cols);
@@ -260,6 +305,7 @@ struct GemmArgs {
     const float* ecoef;
     int erelu;
     long long pstride;    // partial layout: 0 = [chunk][2][N] (row-major); else channel-major, column c at c * pstride + 2 * chunk
+    int c16, ey16;        // bf16 mode with bfloat16 storage: C (and what ACC reads of it) / ey are __bf16 rows
     int precision;        // host side only: PN2_PRECISION_* of the 128-tile contraction (travels with the call, no global state)
     int accumulate;       // EPI_STORE: C += result (PN2_CHAIN_ACCUMULATE_DX): the accumulators START from C -- the loads
                           // travel with the first K-tile's instead of forming a read-modify-write chain in the epilogue
@@ -270,7 +316,7 @@ struct GemmArgs {
 // Epilogue shared by the GEMM kernels: the wave owns NI x NI 32x32 accumulators whose top-left element is
 // (row0, col0); chunk_rows = rows covered by one wave (= one statistics chunk).
 // FULL: the wave's sub-tile lies inside the matrix -- no per-element bounds checks (64 predicated stores otherwise)
-template <int EPI, int NI, bool FULL, bool COH = false>
+template <int EPI, int NI, bool FULL, bool COH = false, bool C16 = false, bool E16 = false>
 __device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& g, f32x16 (&acc)[NI][NI], int row0, int col0, int chunk_rows,
                                               int lane, int split, long long chunk) {
     const int l31 = lane & 31, half = lane >> 5;
@@ -300,12 +346,33 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& g, f32x16 (&a
                 if (FULL || row < g.M) {
                     if (cok) {
                         if (COH && EPI != EPI_SLAB) st_coh(&C[(long long)row * g.ldc + col], val);
+                        else if (C16 && EPI != EPI_SLAB) {
+                            if (!FULL || !kPairedStore) ((__bf16*)C)[(long long)row * g.ldc + col] = (__bf16)val;   // (else: paired stores below)
+                        }
                         else C[(long long)row * g.ldc + col] = val;
                     }
                     sum += val;
                     ++cnt;
                 }
             }
+        if (C16 && EPI != EPI_SLAB && FULL && kPairedStore) {
+            // bfloat16 rows, two columns per store: lanes l and l ^ 1 hold adjacent columns of the same 16 rows; the even lane
+            // writes both columns of the even row of a row pair, the odd lane both columns of the odd row -- 4-byte stores,
+            // half as many of them as 2-byte ones
+            const bool odd = lane & 1;
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const float mine = odd ? acc[i][j][r + 1] : acc[i][j][r];
+                    const float send = odd ? acc[i][j][r] : acc[i][j][r + 1];
+                    const float recv = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(send), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+                    const int row = rbase + 32 * i + (r & 3) + 8 * (r >> 2) + (odd ? 1 : 0);
+                    using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+                    const bf16x2 pr = odd ? bf16x2{(__bf16)recv, (__bf16)mine} : bf16x2{(__bf16)mine, (__bf16)recv};
+                    *(bf16x2*)((__bf16*)C + (long long)row * g.ldc + (col & ~1)) = pr;
+                }
+        }
         // per-(row chunk of WT rows, column) partials; the other half-wave holds the other rows of the column
         if (EPI == EPI_FWD && g.partial) {
             sum += __shfl_xor(sum, 32, 64);
@@ -339,13 +406,30 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& g, f32x16 (&a
             const float mean = g.ecoef[ST_MEAN * g.N + cc], sc = g.ecoef[ST_SCALE * g.N + cc];
             const float bt = g.ecoef[ST_BETA * g.N + cc], invstd = g.ecoef[ST_INVSTD * g.N + cc];
             float s1 = 0.0f, s2 = 0.0f;
+            float eyv[NI][16];
+            if (E16 && FULL) {   // bfloat16 rows, two columns per 4-byte load, the halves exchanged between lanes l and l ^ 1
+                const bool odd = lane & 1;
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const int row = rbase + 32 * i + (r & 3) + 8 * (r >> 2) + (odd ? 1 : 0);
+                        const unsigned u = *(const unsigned*)((const unsigned short*)g.ey + (long long)row * g.ldey + (cc & ~1));
+                        const float lo = __uint_as_float(u << 16), hi = __uint_as_float(u & 0xFFFF0000u);
+                        const float recv = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(odd ? lo : hi), 0xB1, 0xF, 0xF, false));
+                        eyv[i][r] = odd ? recv : lo;        // even lane: its own row r; odd lane: the partner loaded row r
+                        eyv[i][r + 1] = odd ? hi : recv;
+                    }
+            }
 #pragma unroll
             for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = rbase + 32 * i + (r & 3) + 8 * (r >> 2);
                     const int rr = (FULL || row < g.M) ? row : g.M - 1;
-                    const float yy = g.ey[(long long)rr * g.ldey + cc];
+                    const float yy = (E16 && FULL) ? eyv[i][r]
+                                     : E16 ? bf16_to_f32(((const unsigned short*)g.ey)[(long long)rr * g.ldey + cc])
+                                           : g.ey[(long long)rr * g.ldey + cc];
                     const float t = __builtin_fmaf(yy - mean, sc, bt);
                     const float dzh = ((FULL || row < g.M) && (!g.erelu || t > 0.0f)) ? acc[i][j][r] : 0.0f;
                     s1 += dzh;
@@ -367,13 +451,13 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& g, f32x16 (&a
     }
 }
 
-template <int EPI, int NI, bool COH = false>
+template <int EPI, int NI, bool COH = false, bool C16 = false, bool E16 = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[NI][NI], int row0, int col0, int chunk_rows,
                                               int lane, int split, long long chunk) {
     if (row0 + 32 * NI <= g.M && col0 + 32 * NI <= g.N)
-        gemm_epilogue_impl<EPI, NI, true, COH>(g, acc, row0, col0, chunk_rows, lane, split, chunk);
+        gemm_epilogue_impl<EPI, NI, true, COH, C16, E16>(g, acc, row0, col0, chunk_rows, lane, split, chunk);
     else
-        gemm_epilogue_impl<EPI, NI, false, COH>(g, acc, row0, col0, chunk_rows, lane, split, chunk);
+        gemm_epilogue_impl<EPI, NI, false, COH, C16, E16>(g, acc, row0, col0, chunk_rows, lane, split, chunk);
 }
 
 // TEAMS = 4 (64-tiles only): the block holds four 256-thread teams that each contract a quarter of K into their own
@@ -393,7 +477,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[N
 // NTT: threads per K-team -- 256 (four wavefronts, 2 x 2 over the tile), or 64 for the 32 x 32 tile of the smallest problems:
 // ONE wavefront per team, so that a layer of a few hundred rows still spreads over a few hundred compute units (a 64-tile
 // pins 2 * 64 * 64 * K flops to one unit's matrix cores: 1.7 us per K-tile with four teams on it, tools/diag_coop.py).
-template <bool A_T, int A_KIND, bool B_T, int B_KIND, int EPI, int TILE, bool VEC, int TEAMS, bool BF16, bool ACC, bool COH, int NTT, class TAB>
+// ST (bf16 mode with bfloat16 storage, pn2_hip.h PN2_CHAIN_STORE_BF16): bit 0 the A operand's rows, bit 1 the B operand's rows,
+// bit 2 C (and what ACC reads of it), bit 3 the epilogue's ey rows are __bf16.
+template <bool A_T, int A_KIND, bool B_T, int B_KIND, int EPI, int TILE, bool VEC, int TEAMS, bool BF16, bool ACC, bool COH, int NTT, int ST, class TAB>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g0, const TAB& st, const int BX, const int BY, const int BZ,
                                           float* __restrict__ lds) {
     static_assert(NTT == NT || (NTT == 64 && TILE == 32 && TEAMS > 1), "single-wavefront teams are for the 32-tile");
@@ -441,7 +527,25 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g0, const TAB& st, con
         for (int j = 0; j < NI; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    if (ACC && EPI == EPI_STORE && team == 0) {   // uniform per wavefront; the other teams add their partial tiles later
+    if (ACC && EPI == EPI_STORE && (ST & 4) && m0 + wm * WT + 32 * NI <= g.M && n0 + wn * WT + 32 * NI <= g.N) {
+        // bfloat16 C, full sub-tile: two columns per 4-byte load, halves exchanged between lanes l and l ^ 1
+        const bool odd = lane & 1;
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int col = n0 + wn * WT + 32 * j + l31;
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const int row = m0 + wm * WT + 4 * half + 32 * i + (r & 3) + 8 * (r >> 2) + (odd ? 1 : 0);
+                    const unsigned u = *(const unsigned*)((const unsigned short*)g.C + (long long)row * g.ldc + (col & ~1));
+                    const float lo = __uint_as_float(u << 16), hi = __uint_as_float(u & 0xFFFF0000u);
+                    const float recv = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(odd ? lo : hi), 0xB1, 0xF, 0xF, false));
+                    acc[i][j][r] = odd ? recv : lo;
+                    acc[i][j][r + 1] = odd ? hi : recv;
+                }
+            }
+    } else if (ACC && EPI == EPI_STORE && team == 0) {   // uniform per wavefront; the other teams add their partial tiles later
 #pragma unroll
         for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -450,13 +554,16 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g0, const TAB& st, con
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + wm * WT + 4 * half + 32 * i + (r & 3) + 8 * (r >> 2);
-                    if (row < g.M && col < g.N) acc[i][j][r] = g.C[(long long)row * g.ldc + col];
+                    if (row < g.M && col < g.N)
+                        acc[i][j][r] = (ST & 4) ? bf16_to_f32(((const unsigned short*)g.C)[(long long)row * g.ldc + col])
+                                                : g.C[(long long)row * g.ldc + col];
                 }
             }
     }
 
-    Stager<A_T, A_KIND, TILE, VEC, NTT, COH, BF16> sa;
-    Stager<B_T, B_KIND, TILE, VEC, NTT, false, BF16> sb;
+    static_assert(ST == 0 || BF16, "bfloat16 storage belongs to the bf16 mode");
+    Stager<A_T, A_KIND, TILE, VEC, NTT, COH, BF16, (ST & 1) != 0> sa;
+    Stager<B_T, B_KIND, TILE, VEC, NTT, false, BF16, (ST & 2) != 0> sb;
     sa.tid = tid;
     sb.tid = tid;
     sa.prepare(g.A, m0);
@@ -547,16 +654,17 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g0, const TAB& st, con
         }
     }
     if (TEAMS == 1 || team == 0)
-        gemm_epilogue<EPI, NI, COH>(g, acc, m0 + wm * WT, n0 + wn * WT, WT, lane, BZ, (long long)BX * (TILE / WT) + wm);
+        gemm_epilogue<EPI, NI, COH, (ST & 4) != 0, (ST & 8) != 0>(g, acc, m0 + wm * WT, n0 + wn * WT, WT, lane, BZ,
+                                                                  (long long)BX * (TILE / WT) + wm);
 }
 
 // One tile per workgroup: the launch grid is the tile grid.
 template <bool A_T, int A_KIND, bool B_T, int B_KIND, int EPI, int TILE, bool VEC, int TEAMS, bool BF16 = false, bool ACC = false,
-          int NTT = NT>
+          int NTT = NT, int ST = 0>
 __global__ __launch_bounds__(NTT * TEAMS, (NTT == 64 ? 4 : TEAMS > 1 ? 1 : (EPI == EPI_STORE ? PN2_DGRAD_OCC : 3))) void gemm_kernel(const GemmArgs g0,
                                                                                                                         const SegTable st) {
     __shared__ __attribute__((aligned(16))) float lds[TEAMS * 4 * BK * (TILE + 4)];
-    gemm_body<A_T, A_KIND, B_T, B_KIND, EPI, TILE, VEC, TEAMS, BF16, ACC, false, NTT>(g0, st, (int)blockIdx.x, (int)blockIdx.y,
+    gemm_body<A_T, A_KIND, B_T, B_KIND, EPI, TILE, VEC, TEAMS, BF16, ACC, false, NTT, ST>(g0, st, (int)blockIdx.x, (int)blockIdx.y,
                                                                                       (int)blockIdx.z, lds);
 }
 
@@ -582,6 +690,7 @@ struct Act {
     long long ld;
     const float* coef;  // null -> plain
     int relu;
+    int h16;            // the rows are stored as bfloat16 (bf16 mode with bfloat16 storage)
 };
 
 Operand act_operand(const Act& a, int rows, int cols) {
@@ -589,6 +698,7 @@ Operand act_operand(const Act& a, int rows, int cols) {
     o.coef = a.coef;
     o.cstride = cols;
     o.relu = a.relu;
+    o.p16 = a.h16;
     return o;
 }
 

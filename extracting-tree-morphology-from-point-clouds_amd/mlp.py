@@ -71,7 +71,9 @@ class _ChainFn(torch.autograd.Function):
     def forward(ctx, x, meta, *params):
         _hip.require_device(x)
         lib = _hip.lib()
-        x = _hip.f32(x)
+        link = meta.get("link")                         # LazyRows of the producing chain: x is its pre-activation rows
+        if not (link is not None and x.dtype == torch.bfloat16):   # (a linked producer's rows may be bfloat16: STORE_BF16 below)
+            x = _hip.f32(x)
         if x.stride(1) != 1:
             x = x.contiguous()
         rows, cin0 = x.shape
@@ -82,10 +84,22 @@ class _ChainFn(torch.autograd.Function):
         nseg = 1 if seg_ptr is None else len(meta["seg_off"]) - 1
         dev = x.device
         arr = (_hip.MLPLayer * n)()
-        link = meta.get("link")                         # LazyRows of the producing chain: x is its pre-activation rows
         if link is not None:
             arr[0].in_stats, arr[0].in_relu = link.stats.data_ptr(), int(link.relu)
         lazy_out = bool(meta.get("lazy_out"))
+        precision = _PRECISION_CODE[GEMM_PRECISION]
+        # bf16 mode: the large chains keep their pre-BatchNorm rows (and gradient rows) as bfloat16 in memory -- the library says
+        # which chains (include/pn2_hip.h: PN2_CHAIN_STORE_BF16); PN2_BF16_STORAGE=0 keeps fp32 rows (round 2's bf16 mode)
+        cin = cin0
+        for i, spec in enumerate(meta["layers"]):
+            arr[i].cin, arr[i].cout, arr[i].has_bn = cin, spec["cout"], int(spec["has_bn"])
+            cin = spec["cout"]
+        store16 = (GEMM_PRECISION == "bf16" and training and os.environ.get("PN2_BF16_STORAGE", "1") != "0"
+                   and (link is None or x.dtype == torch.bfloat16)          # (linked to fp32 rows: stay fp32)
+                   and bool(lib.pn2_mlp_chain_bf16_storage(rows, arr, n, int(pool_k))))
+        if x.dtype == torch.bfloat16 and not store16:   # a bfloat16 producer feeding a chain that keeps fp32 rows
+            x = x.float()
+        ydtype = torch.bfloat16 if store16 else torch.float32
         ys, stats = [], []
         cin = cin0
         for i, spec in enumerate(meta["layers"]):
@@ -102,7 +116,7 @@ class _ChainFn(torch.autograd.Function):
             if last and not spec["has_bn"] and pool_k <= 1:
                 y = None                                          # the chain writes `out` directly
             else:
-                y = torch.empty(rows, cout, dtype=torch.float32, device=dev)
+                y = torch.empty(rows, cout, dtype=ydtype if spec["has_bn"] else torch.float32, device=dev)
             st = torch.empty(8 * nseg, cout, dtype=torch.float32, device=dev) if spec["has_bn"] else None
             L.y, L.stats = _hip.ptr(y), _hip.ptr(st)
             ys.append(y)
@@ -118,7 +132,8 @@ class _ChainFn(torch.autograd.Function):
             out = torch.empty(rows, cout_last, dtype=torch.float32, device=dev)
             arg = None
         ws = torch.empty(lib.pn2_mlp_workspace_bytes(rows, arr, n, nseg), dtype=torch.uint8, device=dev)
-        precision = _PRECISION_CODE[GEMM_PRECISION]
+        if store16:
+            precision |= _hip.CHAIN_STORE_BF16 | (_hip.CHAIN_X_BF16 if x.dtype == torch.bfloat16 else 0)
         flops = 2 * rows * sum(int(a.cin) * int(a.cout) for a in arr)
         nbytes = 4 * rows * (cin0 + 2 * sum(int(a.cout) for a in arr))
         _hip.call("mlp_chain_fwd", lib.pn2_mlp_chain_fwd_f32, x.data_ptr(), x.stride(0), rows, arr, n, int(training),
@@ -162,6 +177,13 @@ class _ChainFn(torch.autograd.Function):
         params = saved[pos:]
         dev = x.device
         dout = dout.contiguous()
+        store16 = bool(ctx.precision & _hip.CHAIN_STORE_BF16)
+        if dout.dtype == torch.bfloat16 and not store16:
+            dout = dout.float()
+        last = meta["layers"][-1]
+        if store16 and dout.dtype != torch.bfloat16 and last["has_bn"]:
+            dout = dout.to(torch.bfloat16)                 # a bfloat16 chain takes its upstream gradient as bfloat16 rows (the
+                                                           # narrow last layer of a head reads its few fp32 columns itself)
         arr = ctx.arr                                      # the forward's layer table (shapes, weights, y, stats)
         grads = []
         cin, maxc = cin0, 0
@@ -191,11 +213,15 @@ class _ChainFn(torch.autograd.Function):
         if into is not None:
             dx, flags = into, flags | _hip.CHAIN_ACCUMULATE_DX
         else:
-            dx = torch.empty(rows, cin0, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+            dx = torch.empty(rows, cin0, dtype=x.dtype, device=dev) if ctx.needs_input_grad[0] else None   # (bfloat16 for a bfloat16 producer)
             if dx is not None and skip:
                 flags |= _hip.CHAIN_ZERO_LEAD
-        sa = torch.empty(rows * maxc, dtype=torch.float32, device=dev)
-        sb = torch.empty(rows * maxc, dtype=torch.float32, device=dev)
+        if store16:
+            flags |= (_hip.CHAIN_DOUT_BF16 if dout.dtype == torch.bfloat16 else 0) | \
+                     (_hip.CHAIN_DX_BF16 if dx is not None and dx.dtype == torch.bfloat16 else 0)
+        sdt = torch.bfloat16 if store16 else torch.float32
+        sa = torch.empty(rows * maxc, dtype=sdt, device=dev)
+        sb = torch.empty(rows * maxc, dtype=sdt, device=dev)
         seg_ptr, seg_keep = _hip.segments_arg(meta.get("seg_off") if ctx.nseg > 1 else None)
         ws = torch.empty(lib.pn2_mlp_workspace_bytes(rows, arr, n, ctx.nseg), dtype=torch.uint8, device=dev)
         flops = 4 * rows * sum(int(a.cin) * int(a.cout) for a in arr)

@@ -384,6 +384,21 @@ typedef struct pn2_coop {
     int32_t max_workgroups;  /* 0 = default (128) */
 } pn2_coop;
 
+/* bf16 mode with bfloat16 STORAGE (OR-ed into `precision` next to PN2_PRECISION_BF16).  The bf16 mode of the large chains is bound
+ * by HBM, not by the matrix cores, as long as every row tensor is fp32 in memory; with PN2_CHAIN_STORE_BF16 the chain's
+ * pre-BatchNorm rows (every layers[i].y) and, in the backward call, the two scratch buffers hold __bf16 elements (same shapes,
+ * half the bytes); statistics, coefficient blocks, accumulators, weights and weight gradients stay fp32 (the statistics are
+ * taken from the fp32 accumulators before the rows are rounded).  Only chains for which pn2_mlp_chain_bf16_storage() says 1
+ * (every contraction a 128-row-tile kernel, no pooling).  The neighbours of a LINKED chain follow:
+ *   PN2_CHAIN_X_BF16     x (a producing chain's rows, layers[0].in_stats) is __bf16
+ *   PN2_CHAIN_DOUT_BF16  backward: dout is __bf16 (the consumer chain wrote it with PN2_CHAIN_DX_BF16)
+ *   PN2_CHAIN_DX_BF16    backward: dx is written (or, with PN2_CHAIN_ACCUMULATE_DX, read and written) as __bf16 */
+#define PN2_CHAIN_X_BF16 0x1000
+#define PN2_CHAIN_STORE_BF16 0x2000
+#define PN2_CHAIN_DOUT_BF16 0x4000
+#define PN2_CHAIN_DX_BF16 0x8000
+int pn2_mlp_chain_bf16_storage(int rows, const pn2_mlp_layer *layers, int nlayers, int pool_k);
+
 size_t pn2_mlp_workspace_bytes(int rows, const pn2_mlp_layer *layers, int nlayers, int nseg);
 int pn2_mlp_chain_fwd_f32(const float *x, int64_t ldx, int rows, const pn2_mlp_layer *layers, int nlayers,
                           int training, int pool_k, float *out, int32_t *pool_arg, const pn2_segments *segments,
