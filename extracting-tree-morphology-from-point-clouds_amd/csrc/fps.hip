@@ -1127,6 +1127,109 @@ struct alignas(16) ListEntry {
 };
 constexpr int kCap = 16;   // samples accepted per round, at most
 
+// ------------------------------------------------------------------------------------------------------------
+// Small clouds (N <= 2048: every sampled level of the model): ONE wavefront per cloud.  The whole cloud and its running
+// distances sit in one wavefront's registers (PPT points per lane), so a sample is: update + lane best (PPT steps), one DPP
+// arg-max over the 64 lanes, three v_readlane for the winner's coordinates -- no LDS, no workgroup barrier, nothing shared.
+// The four-wavefront kernel above spends its 0.42-0.49 us per sample on exactly those (barrier + LDS hand-over of the
+// wavefront candidates); here a sample of a cloud of <= 256 points is ~0.4 us (256 -> 64 samples: 27 -> 25 us, 64 -> 16: 10.5 ->
+// 7.8 us -- small change, kept because it is also the simplest statement of the algorithm).  Same keys, same tie-breaks
+// (largest distance, then lowest index), same rounding of the distance: bit-identical samples.
+template <int PPT, bool RAGGED>
+__global__ __launch_bounds__(64) void fps_wave_kernel(const float* __restrict__ xyz, int64_t sb, int64_t sn, int64_t sc, int B,
+                                                      int N, int npoint, const int64_t* __restrict__ start,
+                                                      int32_t* __restrict__ out_idx, float* __restrict__ out_xyz,
+                                                      const int* __restrict__ coff) {
+    const int lane = threadIdx.x;
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        const pn2::CloudView cv = RAGGED ? pn2::cloud_view(xyz, sb, sn, sc, N, coff, b, 3)
+                                         : pn2::CloudView{xyz + (int64_t)b * sb, sn, sc, N};
+        const float* p = cv.p;
+        float x[PPT], y[PPT], z[PPT], d[PPT];
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const int n = lane + 64 * j;
+            const bool ok = n < cv.n;
+            const float* q = p + (int64_t)(ok ? n : 0) * cv.sn;
+            x[j] = q[0];
+            y[j] = q[cv.sc];
+            z[j] = q[2 * cv.sc];
+            d[j] = ok ? 1e10f : -1.0f;   // -1 marks a slot beyond N: never a maximum, never updated
+        }
+        int far = (int)start[b];
+        float cx, cy, cz;
+        {
+            const float* c = p + (int64_t)far * cv.sn;
+            cx = c[0];
+            cy = c[cv.sc];
+            cz = c[2 * cv.sc];
+        }
+        for (int i = 0; i < npoint; ++i) {
+            if (lane == 0) {
+                out_idx[(size_t)b * npoint + i] = far;
+                if (out_xyz) {
+                    float* o = out_xyz + ((size_t)b * npoint + i) * 3;
+                    o[0] = cx;
+                    o[1] = cy;
+                    o[2] = cz;
+                }
+            }
+            if (i == npoint - 1) break;
+            float bestd = -1.0f, bx = 0.f, by = 0.f, bz = 0.f;
+            int bestj = 0;
+#pragma unroll
+            for (int j = 0; j < PPT; ++j) {
+                const float dx = __fsub_rn(x[j], cx), dy = __fsub_rn(y[j], cy), dz = __fsub_rn(z[j], cz);
+                const float dist = pn2::norm2(dx, dy, dz);
+                d[j] = dist < d[j] ? dist : d[j];
+                if (d[j] > bestd) {   // strict: the lowest index of this lane wins
+                    bestd = d[j];
+                    bestj = j;
+                    bx = x[j];
+                    by = y[j];
+                    bz = z[j];
+                }
+            }
+            const int bestn = lane + 64 * bestj;
+            const u64 mykey = fps_key(bestd, bestn);
+            int owner;
+            const u64 wkey = wave_max_key_owner(mykey, owner);
+            // all keys zero (npoint > N after every point was taken cannot happen: d >= 0 keeps real keys above the -1 slots)
+            far = (int)(0xFFFFFFFFu - (unsigned)(wkey & 0xFFFFFFFFull));
+            cx = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(bx), owner));
+            cy = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(by), owner));
+            cz = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(bz), owner));
+        }
+    }
+}
+
+constexpr int kWaveMaxN = 256;    // four points per lane: beyond that one wavefront's VALU issue rate (4 cycles per instruction) loses to four
+                                  // wavefronts on four SIMDs despite their barrier (1024 points, 256 samples: 203 us here, 125 us there)
+inline bool use_wave_kernel(int N) { return N <= kWaveMaxN && getenv("PN2_FPS_NO_WAVE") == nullptr; }
+
+template <bool RAGGED>
+int launch_wave(const float* xyz, int64_t sb, int64_t sn, int64_t sc, int B, int N, int npoint, const int64_t* start,
+                int32_t* out_idx, float* out_xyz, const int* coff, hipStream_t s) {
+    const int ppt = pn2::ceil_div(N, 64);
+    const dim3 grid(B < 4096 ? B : 4096), block(64);
+    const double fb = (double)B * (12.0 * N + 8.0 * npoint);
+#define PN2_WAVE_CASE(P)                                                                                                        \
+    if (ppt <= P) {                                                                                                             \
+        PN2_LAUNCH("fps", fb, 0, (fps_wave_kernel<P, RAGGED>), grid, block, s, xyz, sb, sn, sc, B, N, npoint, start, out_idx, out_xyz, \
+                   coff);                                                                                                       \
+    } else
+    PN2_WAVE_CASE(1)
+    PN2_WAVE_CASE(2)
+    PN2_WAVE_CASE(4)
+    PN2_WAVE_CASE(8)
+    PN2_WAVE_CASE(16)
+    PN2_WAVE_CASE(32) { return PN2_E_BADARG; }
+#undef PN2_WAVE_CASE
+    PN2_LAUNCH_CHECK();
+    return 0;
+}
+
+
 // Max over lanes 0..7 / 0..15 (row shifts only), result in every lane.
 __device__ __forceinline__ unsigned max8_u32(unsigned v) {
     v = max(v, pn2::dpp_u32<0x111, 0xF>(0u, v));
@@ -1718,6 +1821,7 @@ extern "C" int pn2_fps_f32(const float* xyz, int64_t sb, int64_t sn, int64_t sc,
         PN2_LAUNCH_CHECK();
         return 0;
     }
+    if (use_wave_kernel(N)) return launch_wave<false>(xyz, sb, sn, sc, B, N, npoint, start, out_idx, out_xyz, nullptr, (hipStream_t)stream);
     const Config c = pick(B, N);
     if (c.G == 0) return PN2_E_BADARG;  // N beyond 64 members x 16384 points (1,048,576)
     const size_t need = pn2_fps_workspace_bytes(B, N, npoint);
@@ -1761,6 +1865,7 @@ extern "C" int pn2_fps_ragged_f32(const float* xyz_cf, const int32_t* coff, int 
         return PN2_E_BADARG;
     if (workspace_bytes < kHdr) return PN2_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
+    if (use_wave_kernel(n_max)) return launch_wave<true>(xyz_cf, 0, 1, 0, C, n_max, npoint, start, out_idx, out_xyz, (const int*)coff, s);
     // one member per cloud: the smallest (points per lane x threads) that covers the longest cloud
     static const int cand[][2] = {{1, 256}, {2, 256}, {4, 256}, {8, 256}, {16, 256}, {4, 1024}, {8, 1024}, {16, 512}, {32, 512}};
     Config c{0, 0, 1, C < 256 ? C : 256, 0.0};
