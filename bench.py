@@ -34,7 +34,7 @@ PMC_NAMES = {"fps": "fps_sorted_kernel", "gemm_fwd": "gemm_kernel<true, 1, true,
              "gemm_wgrad": "gemm_kernel<false, 2, false, 1, 2, 128", "three_interpolate_grad": "tig_reduce_kernel",
              "ball_query": "ball_query_kernel", "three_nn": "three_nn_kernel", "narrow_bwd": "narrow_bwd_kernel",
              "narrow_fwd": "narrow_fwd_kernel"}
-PMC_FILES = [os.path.join(REPO, "profiles", f) for f in ("r02_pmc_traffic.json", "r01_pmc_traffic.json")]
+PMC_FILES = [os.path.join(REPO, "profiles", f) for f in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")]
 
 
 def pmc_traffic(kernel):

@@ -92,5 +92,34 @@ rast = {"points": N, "rasters": stream.flat["rasters"], "mini_batches": len(stre
                          "sample": f"the reference's loops (box masks over the cloud, host padding) on the first {sub} points "
                                    f"({len(b)} boxes, {len(mb)} mini-batches), numpy, {t_cpu_r:.2f} s"},
         "gpu_over_cpu": (N / t_rast) / (sub / t_cpu_r)}
+# ---- BASELINE configs[4] on one GPU: predict_all_trees + kNN-to-QSM projection over a synthetic forest of 100 trees x ~8 000 points
+# (two depth-5 models per tree through forward_hierarchical_streaming, 1 m rasters, mini-batches of 60, then the cylinder
+# projection of the executed cloud): trees per second of ONE rank -- the sharded run hands each of the 8 ranks 12-13 of these trees.
+from pn2_amd import predict  # noqa: E402
+from pn2_amd.PointNet2.PointNet2 import PointNet2  # noqa: E402
+
+n_trees = 100
+trees, qsms = [], []
+for t in range(n_trees):
+    n_t = 7000 + 20 * t
+    txyz, _, _ = gaussian_branch_tree(n_t, seed=100 + t)
+    trees.append(txyz.astype(np.float64))
+    r2 = np.random.default_rng(t)
+    m = 200
+    st_ = txyz[r2.integers(0, n_t, m)]
+    en_ = st_ + r2.normal(size=(m, 3)) * 0.4
+    qsms.append({"startX": st_[:, 0], "startY": st_[:, 1], "startZ": st_[:, 2], "endX": en_[:, 0], "endY": en_[:, 1], "endZ": en_[:, 2],
+                 "radius": r2.uniform(0.02, 0.3, m), "ID": np.arange(m)})
+torch.manual_seed(0)
+m_off, m_noise = PointNet2(depth=5).cuda().eval(), PointNet2(depth=5).cuda().eval()
+predict.predict_forest(m_off, m_noise, trees[:3], qsms[:3], seed=0)          # warm-up
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+res = predict.predict_forest(m_off, m_noise, trees, qsms, seed=0)
+torch.cuda.synchronize()
+t_forest = time.perf_counter() - t0
+forest = {"trees": n_trees, "points": int(sum(len(t) for t in trees)), "seconds": t_forest, "trees_per_s": n_trees / t_forest,
+          "points_per_s": sum(len(t) for t in trees) / t_forest,
+          "note": "one rank, host arrays in, numpy results out (BASELINE configs[4] shape; the 8-GPU run shards the trees, no collective)"}
 print(json.dumps({"metric": "data path either side of the hot path (SURVEY 8 f-1 raster stream, f-2 cylinder projection), points/s",
-                  "projection": proj, "raster_stream": rast, "dtype": "f32", "data": "synthetic"}))
+                  "projection": proj, "raster_stream": rast, "forest_prediction_configs4": forest, "dtype": "f32", "data": "synthetic"}))

@@ -2,7 +2,7 @@
 #   gpurun --timeout 1100 -- 'bash tools/profile_round.sh r02'
 # then copy gpurun_out/round/* into profiles/ with the round prefix (tools/collect_profiles.py).
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/round
 mkdir -p $O
@@ -16,6 +16,11 @@ timeout -k 10 300 python bench.py --dtype bf16 --no-cpu-baseline > $O/bench_bf16
 timeout -k 10 300 python bench.py --mode rasterized --dtype bf16 --no-cpu-baseline > $O/bench_rasterized_bf16.json 2>> $O/bench.err
 timeout -k 10 300 python bench.py --trees 8 --points 65536 --no-cpu-baseline > $O/bench_cfg3_8x65536.json 2>> $O/bench.err
 timeout -k 10 300 python bench.py --depth 5 --no-cpu-baseline > $O/bench_depth5.json 2>> $O/bench.err
+PN2_NO_COOP=1 timeout -k 10 300 python bench.py --no-cpu-baseline > $O/bench_no_coop.json 2>> $O/bench.err
+PN2_COOP_MAX_ROWS=10000 timeout -k 10 300 python bench.py --no-cpu-baseline > $O/bench_coop_all_levels.json 2>> $O/bench.err
+PN2_NO_TILE32=1 PN2_NO_COOP=1 timeout -k 10 300 python bench.py --no-cpu-baseline > $O/bench_no_tile32.json 2>> $O/bench.err
+PN2_BF16_STORAGE=0 timeout -k 10 300 python bench.py --dtype bf16 --no-cpu-baseline > $O/bench_bf16_fp32_rows.json 2>> $O/bench.err
+PN2_DIST_BACKEND=gloo timeout -k 10 300 python bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_gloo2_selfspawn.json 2>> $O/bench.err
 echo "bench variants done"
 fi
 cd /tmp && export TMPDIR=/tmp
@@ -34,5 +39,7 @@ cd $R
 timeout -k 10 600 python tools/bench_features.py > $O/bench_features.json 2>> $O/bench.err
 timeout -k 10 300 python tools/bench_datapath.py > $O/bench_datapath.json 2>> $O/bench.err
 timeout -k 10 300 python tools/bench_serialization.py > $O/bench_serialization.json 2>> $O/bench.err
+timeout -k 10 300 python tools/bench_ptv3_attention.py > $O/bench_ptv3_attention.json 2>> $O/bench.err
+timeout -k 10 300 python tools/bench_chain.py --reps 50 > $O/bench_chain.txt 2>> $O/bench.err
 echo "secondary benches done"
 ls -la $O
