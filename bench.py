@@ -204,6 +204,9 @@ def main(argv=None):
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="f32 = the reference's arithmetic (parity mode); bf16 = bfloat16 MFMA operands with fp32 accumulation in the "
                          "large contractions (throughput mode, BASELINE configs[1]; tolerance: tests/test_bf16_mode.py)")
+    ap.add_argument("--graph", action="store_true",
+                    help="monolithic, 1 GPU: the whole step (zero grads, forward, loss, backward, AdamW) captured once as ONE HIP graph "
+                         "and replayed per step with fresh FPS start indices (pn2_amd/graphs.py) -- same kernels, no host launch path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dump-groups", default=None, help="write every (kernel, launch shape) group of the instrumented run here")
     args = ap.parse_args(argv)
@@ -229,7 +232,9 @@ def main(argv=None):
     model = PointNet2(depth=depth, loss_multiplier_semantic=0).to(dev).train()
     # parameters and gradients live in two flat, 16-byte-aligned buffers: one all-reduce and ONE fused AdamW launch per step
     grads = parallel.FlatGradAllReduce(model, flatten_params=True)
-    opt = torch.optim.AdamW(grads.optimizer_params(), lr=0.01, weight_decay=1e-3, fused=True)   # train_PointNet2.py:250
+    use_graph = args.graph and world == 1 and not rasterized
+    opt = torch.optim.AdamW(grads.optimizer_params(), lr=0.01, weight_decay=1e-3, fused=True,   # train_PointNet2.py:250
+                            capturable=use_graph)
     if rasterized:
         stream, labels, padded, n_rasters = make_raster_stream(args.points, seed=rank, device=dev)
     else:
@@ -256,6 +261,11 @@ def main(argv=None):
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    step_eager = step
+    if use_graph:
+        from pn2_amd.graphs import GraphedTrainStep
+        step = GraphedTrainStep(step_eager, warmup=2)
+
     for _ in range(args.warmup):
         step()
     barrier()
@@ -275,7 +285,7 @@ def main(argv=None):
     # launch stream (pn2_prof_enable) and aggregates per (kernel, launch shape)
     def timed_steps():
         for _ in range(args.steps):
-            step()
+            step_eager()                                  # (eager: a graph replay makes no library calls to bracket)
         torch.cuda.synchronize()
     groups = _hip.kernel_profile(timed_steps)
     barrier()
@@ -350,7 +360,7 @@ def main(argv=None):
             "value": args.points * args.trees * world * args.steps / dt, "unit": "points/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": workload, "mode": args.mode, "points_per_gpu": args.points * args.trees,
+            "config": {"workload": workload, "mode": args.mode, "hip_graph": bool(use_graph), "points_per_gpu": args.points * args.trees,
                        "trees_per_gpu": args.trees, "depth": depth,
                        "parallelism": f"dp{world} ({args.trees} tree(s) per rank, 1 flat gradient all-reduce per step)"},
             "roofline": roofline, "kernels": kernels, "rooflines": rooflines,

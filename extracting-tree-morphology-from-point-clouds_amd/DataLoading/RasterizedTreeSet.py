@@ -2,8 +2,9 @@
 (Modules/DataLoading/RasterizedTreeSet.py:150-459), with the rasterisation and the collate done on the device
 (rasters.py, csrc/raster.hip) instead of O(#rasters x N) boolean masks and per-mini-batch host padding.
 
-Differences, all documented in rasters.py: the box grid is recomputed from the cloud (raster_size / stride are
-constructor arguments; the reference reads the same boxes from the JSON written by rasterize_clouds), and
+Differences, all documented in rasters.py: the box grid comes from the boxes stored in the JSON when it carries them (like
+the reference, RasterizedTreeSet.py:228-238) and is computed from the cloud with the constructor's raster_size / stride
+otherwise, and
 `collate_fn_streaming` returns a re-iterable list of mini-batches instead of a one-shot generator (the
 reference's second model of predict_*_PointNet2.py sees an exhausted generator).
 """
@@ -90,8 +91,14 @@ class RasterizedTreeSet_Hierarchical(Dataset):
         return len(self.tree_keys)
 
     def __getitem__(self, idx):
-        data = load_cloud(self.data[self.tree_keys[idx]]["path"])
-        return self.from_array(data)
+        entry = self.data[self.tree_keys[idx]]
+        item = self.from_array(load_cloud(entry["path"]))
+        if entry.get("rasters"):
+            # the JSON's own boxes decide (the reference reads them, RasterizedTreeSet.py:228-238) -- not the constructor's
+            # raster_size / stride, which only serve clouds that come without metadata
+            bounds, size, stride = rasters.bounds_from_metadata(entry["rasters"])
+            item["raster_grid"] = (bounds, size, stride if stride is not None else size)
+        return item
 
     def from_array(self, data):
         """The body of the reference's __getitem__ (:201-268) for a cloud that is already in memory: columns
@@ -103,8 +110,9 @@ class RasterizedTreeSet_Hierarchical(Dataset):
 
     def collate_fn_streaming(self, batch):
         tree = batch[0]
-        stream = rasters.build_stream(tree["points"], tree["features"], tree["offset_mask"], self.raster_size, self.stride,
-                                      self.minibatch_size)
+        bounds, size, stride = tree.get("raster_grid", (None, self.raster_size, self.stride))
+        stream = rasters.build_stream(tree["points"], tree["features"], tree["offset_mask"], size, stride, self.minibatch_size,
+                                      bounds=bounds)
         return {"mini_batches": stream, "cloud_length": tree["cloud_length"], "offset_labels": tree["offset_labels"],
                 "semantic_labels": tree["semantic_labels"]}
 

@@ -95,10 +95,28 @@ def rasterize_points(points, raster_size=1.0, stride=1.0, bounds=None):
     return ids, lengths.cpu().tolist(), boxes, (nx, ny, nz), bounds
 
 
-def build_stream(points, features, offset_mask, raster_size=1.0, stride=1.0, minibatch_size=20):
+def bounds_from_metadata(raster_entries):
+    """The per-axis grid behind the boxes rasterize_clouds stored in its JSON ({"bounds": {"min": [...], "max": [...]}} per
+    non-empty raster, ModelPredicting.py:133-149 / RasterizeClouds.py:52-97) -> (bounds as grid_bounds returns them, raster
+    size, stride or None).  The reference's dataset takes the boxes from the JSON (RasterizedTreeSet.py:228-238), whatever
+    raster_size / stride wrote them; so does the mirror when the JSON carries them."""
+    lo = np.array([r["bounds"]["min"] for r in raster_entries], dtype=np.float64)
+    hi = np.array([r["bounds"]["max"] for r in raster_entries], dtype=np.float64)
+    size = float(np.median(hi - lo))
+    out, strides = [], []
+    for a in range(3):
+        vals = np.unique(lo[:, a])
+        if len(vals) > 1:
+            strides.append(float(np.min(np.diff(vals))))
+        out.append((vals.astype(np.float32), (vals + size).astype(np.float32), vals))
+    return out, size, (min(strides) if strides else None)
+
+
+def build_stream(points, features, offset_mask, raster_size=1.0, stride=1.0, minibatch_size=20, bounds=None):
     """The tree as forward_hierarchical_streaming expects it: -> RasterStream (see class).  points [N,3], features [N,F]
-    (or None), offset_mask [N] bool, all on the device."""
-    ids, lengths, boxes, dims, bounds = rasterize_points(points, raster_size, stride)
+    (or None), offset_mask [N] bool, all on the device.  bounds: the grid to use instead of the one computed from the cloud
+    (bounds_from_metadata: boxes stored by rasterize_clouds)."""
+    ids, lengths, boxes, dims, bounds = rasterize_points(points, raster_size, stride, bounds=bounds)
     stream = RasterStream()
     if not lengths:
         return stream
