@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..mlp import chain_rows
+from ..mlp import chain_rows, hoist_ok, hoisted_conv, interp_bn_rows
 from .pointnet2_utils import *  # noqa: F401,F403  (the reference re-exports the L0 ops from here)
 from .pointnet2_utils import _sample_and_group_i32, _draw_start
 
@@ -164,14 +164,22 @@ class PointNetFeaturePropagation(nn.Module):
         p1 = None if points1 is None else points1.permute(0, 2, 1)
         B, N, _ = x1.shape
         S = x2.shape[1]
+        layers = [(c, b, True) for c, b in zip(self.mlp_convs, self.mlp_bns)]
         if S == 1:
             feats = p2.repeat(1, N, 1)
             if p1 is not None:
                 feats = torch.cat([p1, feats], dim=-1)
         else:
             idx, w = ops.three_nn(x1, x2)
-            feats = ops.ThreeInterpolateConcat.apply(p1, p2, idx, w)
-        y = chain_rows(feats.reshape(B * N, -1), [(c, b, True) for c, b in zip(self.mlp_convs, self.mlp_bns)], lazy_out=lazy_rows)
+            if p1 is None and hoist_ok(self.mlp_convs[0], self.mlp_bns[0], len(self.mlp_convs), x1.device):
+                # no skip connection (fp1): conv(interp(P)) = interp(conv(P)) -- the first contraction runs over the B*S sampled
+                # rows, the interpolation carries the layer's BatchNorm statistics (mlp.interp_bn_rows)
+                q = hoisted_conv(p2.reshape(B * S, -1), self.mlp_convs[0])
+                feats = interp_bn_rows(q.view(B, S, -1), idx, w, self.mlp_bns[0], bias=self.mlp_convs[0].bias)
+                layers = layers[1:]
+            else:
+                feats = ops.ThreeInterpolateConcat.apply(p1, p2, idx, w).reshape(B * N, -1)
+        y = chain_rows(feats.reshape(B * N, -1) if torch.is_tensor(feats) else feats, layers, lazy_out=lazy_rows)
         if lazy_rows:
             return y, B, N
         return y.view(B, N, -1).permute(0, 2, 1)

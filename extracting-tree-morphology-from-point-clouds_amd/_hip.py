@@ -123,6 +123,9 @@ SIGNATURES = {
     "pn2_mlp_chain_fwd_f32": (_int, [_vp, _i64, _int, _lp, _int, _int, _int, _vp, _vp, _sp, _int, _cp, _vp, _sz, _vp]),
     "pn2_mlp_link_partial_bytes": (_sz, [_int, _int, _int, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "pn2_mlp_reduce_wgrad": (_int, [ctypes.POINTER(WgradTask), _int, _vp]),
+    "pn2_interp_bn_workspace_bytes": (_sz, [_int, _int, _int, _int, _int]),
+    "pn2_interp_bn_fwd_f32": (_int, [_vp, _vp, _vp, _int, _int, _int, _lp, _sp, _vp, _vp, _sz, _vp]),
+    "pn2_interp_bn_bwd_f32": (_int, [_vp, _vp, _vp, _int, _int, _int, _lp, _vp, _sp, _vp, _sz, _vp]),
     "pn2_mlp_chain_bwd_f32": (_int, [_vp, _i64, _int, _lp, _int, _int, _vp, _vp, _vp, _i64, _int, _vp, _vp, _sp, _int, _tp, _cp, _vp,
                                      _sz, _vp]),
     "pn2_cylinder_project_f32": (_int, [_vp, _i64, _int, _vp, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _vp]),
@@ -142,7 +145,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 4                      # PN2_ABI_VERSION of include/pn2_hip.h
+ABI_VERSION = 5                      # PN2_ABI_VERSION of include/pn2_hip.h
 CHAIN_ACCUMULATE_DX = 0x100          # PN2_CHAIN_ACCUMULATE_DX
 CHAIN_LAZY_OUT = 0x400               # PN2_CHAIN_LAZY_OUT
 CHAIN_ZERO_LEAD = 0x800              # PN2_CHAIN_ZERO_LEAD

@@ -1792,3 +1792,175 @@ extern "C" int pn2_mlp_reduce_wgrad(const pn2_wgrad_task* tasks, int n, void* st
     PN2_LAUNCH_CHECK();
     return 0;
 }
+
+// ================================================================== feature propagation, first convolution hoisted
+// (pn2_hip.h "Feature propagation with the first convolution HOISTED").  Forward: one workgroup interpolates a block of R rows
+// of the C-wide layer -- a thread owns four channels of IB_PASSES rows per statistics chunk -- writes them and reduces the two
+// chunks' (mean, M2) from the registers (two-pass inside the chunk, as the GEMM epilogue does).  Backward: three_nn.hip's
+// bucketed scatter with the TR_DY transform on its loads (interp.h).
+#include "interp.h"
+
+namespace {
+
+constexpr int IB_PASSES = 8;
+inline int interp_block_rows(int C) { return 2 * IB_PASSES * (256 / (C / 4)); }   // 256 / 128 / 64 rows at C = 64 / 128 / 256
+
+__global__ __launch_bounds__(256) void interp_stats_kernel(const float* __restrict__ q, const int32_t* __restrict__ idx,
+                                                           const float* __restrict__ w, int N, int S, int C,
+                                                           float* __restrict__ y, float* __restrict__ partial, long long pchunk,
+                                                           long long pcol, long long pwhich, const SegTable st, int32_t* status) {
+    __shared__ float red[1024];    // [rows per pass][C]
+    __shared__ float smean[256];
+    const int tpr = C / 4, rpp = 256 / tpr, ch = IB_PASSES * rpp;
+    const int cg = threadIdx.x % tpr, rs = threadIdx.x / tpr, c = 4 * cg;
+    const RowBlock rb = row_block(st, (int)blockIdx.x, 2 * ch);
+    for (int h = 0; h < 2; ++h) {
+        const int base = rb.row0 + h * ch;
+        const int left = rb.row_end - base;
+        const int cnt = left < 0 ? 0 : (left < ch ? left : ch);
+        float4 v[IB_PASSES];
+#pragma unroll
+        for (int p = 0; p < IB_PASSES; ++p) {
+            const int row = base + p * rpp + rs;
+            v[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < rb.row_end) {
+                const long long r3 = 3ll * row;
+                int j0 = idx[r3], j1 = idx[r3 + 1], j2 = idx[r3 + 2];
+                if (((unsigned)j0 >= (unsigned)S) | ((unsigned)j1 >= (unsigned)S) | ((unsigned)j2 >= (unsigned)S)) {
+                    if (status) atomicOr(status, PN2_STATUS_BAD_INDEX);   // untrusted index: row 0 instead, and say so
+                    j0 = (unsigned)j0 < (unsigned)S ? j0 : 0;
+                    j1 = (unsigned)j1 < (unsigned)S ? j1 : 0;
+                    j2 = (unsigned)j2 < (unsigned)S ? j2 : 0;
+                }
+                const float w0 = w[r3], w1 = w[r3 + 1], w2 = w[r3 + 2];
+                const float* qb = q + (long long)(row / N) * S * C + c;
+                const float4 a = *(const float4*)(qb + (long long)j0 * C);
+                const float4 b = *(const float4*)(qb + (long long)j1 * C);
+                const float4 d = *(const float4*)(qb + (long long)j2 * C);
+                // the reference's order (blocks.py:204): (p0*w0 + p1*w1) + p2*w2, separate multiplies and adds
+                v[p].x = __fadd_rn(__fadd_rn(__fmul_rn(a.x, w0), __fmul_rn(b.x, w1)), __fmul_rn(d.x, w2));
+                v[p].y = __fadd_rn(__fadd_rn(__fmul_rn(a.y, w0), __fmul_rn(b.y, w1)), __fmul_rn(d.y, w2));
+                v[p].z = __fadd_rn(__fadd_rn(__fmul_rn(a.z, w0), __fmul_rn(b.z, w1)), __fmul_rn(d.z, w2));
+                v[p].w = __fadd_rn(__fadd_rn(__fmul_rn(a.w, w0), __fmul_rn(b.w, w1)), __fmul_rn(d.w, w2));
+                *(float4*)(y + (long long)row * C + c) = v[p];
+            }
+        }
+        float4 s = v[0];
+#pragma unroll
+        for (int p = 1; p < IB_PASSES; ++p) s.x += v[p].x, s.y += v[p].y, s.z += v[p].z, s.w += v[p].w;
+        *(float4*)(red + rs * C + c) = s;
+        __syncthreads();
+        if (rs == 0) {
+            for (int k = 1; k < rpp; ++k) {
+                const float4 o = *(const float4*)(red + k * C + c);
+                s.x += o.x, s.y += o.y, s.z += o.z, s.w += o.w;
+            }
+            const float inv = cnt > 0 ? 1.0f / (float)cnt : 0.0f;
+            *(float4*)(smean + c) = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
+        }
+        __syncthreads();
+        const float4 m = *(const float4*)(smean + c);
+        float4 m2 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int p = 0; p < IB_PASSES; ++p) {
+            if (base + p * rpp + rs < rb.row_end) {
+                const float dx = v[p].x - m.x, dy = v[p].y - m.y, dz = v[p].z - m.z, dw = v[p].w - m.w;
+                m2.x += dx * dx, m2.y += dy * dy, m2.z += dz * dz, m2.w += dw * dw;
+            }
+        }
+        *(float4*)(red + rs * C + c) = m2;
+        __syncthreads();
+        if (rs == 0) {
+            for (int k = 1; k < rpp; ++k) {
+                const float4 o = *(const float4*)(red + k * C + c);
+                m2.x += o.x, m2.y += o.y, m2.z += o.z, m2.w += o.w;
+            }
+            const long long chunk = 2ll * blockIdx.x + h;
+            const float mm[4] = {m.x, m.y, m.z, m.w}, qq[4] = {m2.x, m2.y, m2.z, m2.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float* pp = partial + chunk * pchunk + (long long)(c + j) * pcol;
+                pp[0] = cnt > 0 ? mm[j] : 0.0f;
+                pp[pwhich] = cnt > 0 ? qq[j] : 0.0f;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+bool interp_bn_args_ok(const void* idx, const void* w, int B, int N, int S, const pn2_mlp_layer* L, const pn2_segments* sg) {
+    if (!idx || !w || !L || B <= 0 || N <= 0 || S <= 0 || (long long)B * N >= (1ll << 31) / 4) return false;
+    if (!(L->cout == 64 || L->cout == 128 || L->cout == 256) || !L->has_bn || !L->y || !L->stats || !aligned16(L->y)) return false;
+    if (!segs_valid(B * N, sg, 1)) return false;
+    for (int i = 0; sg && sg->nseg > 1 && i <= sg->nseg; ++i)
+        if (sg->row_off[i] % N) return false;   // whole clouds per segment
+    return true;
+}
+
+}  // namespace
+
+extern "C" size_t pn2_interp_bn_workspace_bytes(int B, int N, int S, int C, int nseg) {
+    if (B <= 0 || N <= 0 || S <= 0 || C <= 0) return 0;
+    if (nseg < 1) nseg = 1;
+    const long long rows = (long long)B * N;
+    const size_t part = ((size_t)pn2::ceil_div(rows, 32) + 2 * (size_t)nseg) * 2 * (size_t)C * sizeof(float);
+    return slice_region_bytes((int)rows, nseg, (size_t)C) + align256(part) + align256(pn2::interp::grad_workspace_bytes(B, rows, S));
+}
+
+extern "C" int pn2_interp_bn_fwd_f32(const float* q, const int32_t* idx, const float* w, int B, int N, int S,
+                                     const pn2_mlp_layer* layer, const pn2_segments* segments, int32_t* status, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+    if (!q || !aligned16(q) || !interp_bn_args_ok(idx, w, B, N, S, layer, segments)) return PN2_E_BADARG;
+    const pn2_mlp_layer& L = *layer;
+    const int rows = B * N, C = L.cout;
+    const Segs Sg = make_segs(rows, segments);
+    if (!workspace || workspace_bytes < pn2_interp_bn_workspace_bytes(B, N, S, C, Sg.nseg)) return PN2_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const FinScratch fs = fin_scratch(workspace, Sg.nseg, (size_t)C);
+    float* part = (float*)((char*)workspace + slice_region_bytes(rows, Sg.nseg, (size_t)C));
+    const int R = interp_block_rows(C);
+    int nblk = 0;
+    const SegTable st = make_table(Sg, R, &nblk);
+    const long long cm = cm_stride(rows, R, Sg.nseg);
+    PN2_LAUNCH("interp_bn_fwd", (double)rows * (36.0 + 4.0 * C) + 4.0 * B * S * C, 0, interp_stats_kernel, dim3(nblk), dim3(256), s,
+               q, idx, w, N, S, C, L.y, part, cm ? 2ll : 2ll * C, cm ? cm : 1ll, cm ? 1ll : (long long)C, st, status);
+    PN2_LAUNCH_CHECK();
+    return launch_bn_finalize(part, fs, Sg, R, rows, L, s, cm);
+}
+
+extern "C" int pn2_interp_bn_bwd_f32(const float* dout, const int32_t* idx, const float* w, int B, int N, int S,
+                                     const pn2_mlp_layer* layer, float* dq, const pn2_segments* segments, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+    if (!dout || !dq || !aligned16(dout) || !interp_bn_args_ok(idx, w, B, N, S, layer, segments)) return PN2_E_BADARG;
+    const pn2_mlp_layer& L = *layer;
+    const int rows = B * N, C = L.cout;
+    const Segs Sg = make_segs(rows, segments);
+    if (!workspace || workspace_bytes < pn2_interp_bn_workspace_bytes(B, N, S, C, Sg.nseg)) return PN2_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const FinScratch fs = fin_scratch(workspace, Sg.nseg, (size_t)C);
+    char* base = (char*)workspace + slice_region_bytes(rows, Sg.nseg, (size_t)C);
+    float* part = (float*)base;
+    const size_t part_bytes = align256(((size_t)pn2::ceil_div(rows, 32) + 2 * (size_t)Sg.nseg) * 2 * (size_t)C * sizeof(float));
+    // BatchNorm-backward sums: left behind by the linked consumer's dgrad epilogue, or reduced here
+    const float* partial = part;
+    int R = RB, cpb = 1, st_;
+    long long cm = 0;
+    if (L.out_partial) {
+        partial = L.out_partial;
+        R = L.out_partial_rows;
+        cpb = L.out_partial_cpb;
+        if (R <= 0 || cpb != 2) return PN2_E_BADARG;
+        cm = cm_stride(rows, R, Sg.nseg);
+    } else {
+        int nblk = 0;
+        const SegTable tb = make_table(Sg, RB, &nblk);
+        PN2_LAUNCH("bn_bwd_reduce", 8.0 * rows * C, 0, (bn_bwd_reduce_kernel<true>), dim3(nblk), dim3(256), s, dout, (long long)C,
+                   (const float*)L.y, (long long)C, rows, C, (const float*)L.stats, L.relu, part, tb, 0, 0);
+        PN2_LAUNCH_CHECK();
+    }
+    if ((st_ = launch_bn_bwd_finalize(partial, fs, Sg, R, cpb, rows, L, s, cm))) return st_;
+    int32_t one[2] = {0, rows};
+    const pn2::interp::DySource dy{L.y, L.stats, L.relu, Sg.nseg, Sg.nseg > 1 ? Sg.row_off : one};
+    return pn2::interp::grad(dout, C, 0, idx, w, B, N, S, C, dq, base + part_bytes, workspace_bytes - (size_t)(base + part_bytes - (char*)workspace),
+                             s, nullptr, rows, &dy);
+}

@@ -9,7 +9,9 @@
 //
 // three_interpolate: out = (p[i0]*w0 + p[i1]*w1) + p[i2]*w2 with separate multiplies and adds, 16-byte
 // vectorised over channels, written straight into the (optional) skip-connection concat buffer.
+#include "interp.h"
 #include "pn2_common.h"
+#include "segments.h"
 #include <cstdlib>
 
 namespace {
@@ -405,11 +407,21 @@ __global__ __launch_bounds__(TIG_T) void tig_fill_kernel(const int32_t* __restri
 // 16 table slots: the table is what limits the wavefronts -- and with them the bytes in flight -- per compute unit (32 slots:
 // 120 us at 262 144 x 1024 x 128, 16: 100 us; scattered neighbours beyond the table go to memory as atomics)
 constexpr int TIG_SLOTS = 16;
+// DY: `dout` is the gradient with respect to relu(bn(y)); the row that is scattered is the BatchNorm(+ReLU) backward of it,
+// dz = scale * (mask(dout) - a - (y - mean) * b) -- the TR_DY operand transform of the chain GEMMs (mlp_tile.h) applied to
+// the two channels a lane owns.  The rows of one destination belong to one cloud, hence to one segment: its coefficient
+// block is picked once per wavefront.
+struct TigDy {
+    const float* y;
+    const float* coef;
+    int relu;
+};
+template <bool DY>
 __global__ __launch_bounds__(kBlock) void tig_reduce_kernel(const float* __restrict__ dout, int64_t out_stride, int64_t out_offset,
                                                             const int32_t* __restrict__ idx, const float* __restrict__ w,
                                                             const int* __restrict__ offs, const int* __restrict__ coffs,
                                                             const int* __restrict__ list, int BS, int S, int D,
-                                                            float* __restrict__ dpoints2) {
+                                                            float* __restrict__ dpoints2, const TigDy dy, const SegTable st) {
     __shared__ float tab[kBlock / 64][TIG_SLOTS][128];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (kBlock / 64) + wv));
@@ -422,9 +434,20 @@ __global__ __launch_bounds__(kBlock) void tig_reduce_kernel(const float* __restr
     const int dest = lo_d, cloud_base = (dest / S) * S;
     const int lo = offs[dest] + (wave - coffs[dest]) * TIG_CHUNK, end = offs[dest + 1];
     const int hi = lo + TIG_CHUNK < end ? lo + TIG_CHUNK : end;
+    const float* coef = dy.coef;
+    if (DY && st.nseg > 1 && lo < hi) coef += (long long)seg_of_row(st, __builtin_amdgcn_readfirstlane(list[lo])) * ST_ROWS * D;
     for (int c0 = 0; c0 < D; c0 += 128) {
         float a0 = 0.0f, a1 = 0.0f;
         const int ca = c0 + lane, cb = c0 + 64 + lane;
+        float km[2], ks[2], kb[2], ka[2], kq[2];    // DY: the coefficients of channels ca, cb
+        if (DY) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int cc = (h ? cb : ca) < D ? (h ? cb : ca) : D - 1;
+                km[h] = coef[ST_MEAN * D + cc], ks[h] = coef[ST_SCALE * D + cc], kb[h] = coef[ST_BETA * D + cc];
+                ka[h] = coef[ST_A * D + cc], kq[h] = coef[ST_B * D + cc];
+            }
+        }
         int tag = -1, nslots = 0;          // lane s < nslots: destination held by table slot s
         constexpr int U = 4;               // rows in flight: their ids, neighbour lists and data are fetched together
         for (int e0 = lo; e0 < hi; e0 += U) {
@@ -437,6 +460,14 @@ __global__ __launch_bounds__(kBlock) void tig_reduce_kernel(const float* __restr
                 const float* src = dout + (long long)row[u] * out_stride + out_offset;
                 v0[u] = ca < D ? src[ca] : 0.0f;
                 v1[u] = cb < D ? src[cb] : 0.0f;
+                if (DY) {
+                    const float* yr = dy.y + (long long)row[u] * D;
+                    const float y0 = ca < D ? yr[ca] : 0.0f, y1 = cb < D ? yr[cb] : 0.0f;
+                    const float t0 = __builtin_fmaf(y0 - km[0], ks[0], kb[0]), t1 = __builtin_fmaf(y1 - km[1], ks[1], kb[1]);
+                    const float g0 = (!dy.relu || t0 > 0.0f) ? v0[u] : 0.0f, g1 = (!dy.relu || t1 > 0.0f) ? v1[u] : 0.0f;
+                    v0[u] = ca < D ? ks[0] * (g0 - ka[0] - (y0 - km[0]) * kq[0]) : 0.0f;
+                    v1[u] = cb < D ? ks[1] * (g1 - ka[1] - (y1 - km[1]) * kq[1]) : 0.0f;
+                }
                 const int32_t* ir = idx + (long long)row[u] * 3;
                 const float* wr = w + (long long)row[u] * 3;
                 i1[u] = ir[1], i2[u] = ir[2];
@@ -629,11 +660,14 @@ extern "C" size_t pn2_three_interpolate_grad_workspace_bytes(int B, int N, int S
 // packed rows in total).  Ragged batches always take the bucketed path.
 static int tig_run(const float* dout, int64_t out_stride, int64_t out_offset, const int32_t* idx, const float* w, int B, int N,
                    int S, int D, float* dpoints2, void* workspace, size_t workspace_bytes, void* stream, const int* coff,
-                   long long rows) {
+                   long long rows, const pn2::interp::DySource* dy = nullptr) {
     hipStream_t s = (hipStream_t)stream;
+    if (dy && (!dy->y || !dy->coef || out_stride != D || out_offset != 0 || S > 8192 || B > 65535 || dy->nseg > kMaxSegs ||
+               (dy->nseg > 1 && !dy->row_off)))
+        return PN2_E_BADARG;
     PN2_HIP_CHECK(hipMemsetAsync(dpoints2, 0, (size_t)B * S * D * sizeof(float), s));
-    const double bytes = (double)rows * (36.0 + 4.0 * D) + 4.0 * B * S * D;
-    if (!coff && !tig_sorted(B, N, S, D)) {
+    const double bytes = (double)rows * (36.0 + (dy ? 8.0 : 4.0) * D) + 4.0 * B * S * D;
+    if (!dy && !coff && !tig_sorted(B, N, S, D)) {
         const long long total = (long long)B * N * D;
         PN2_LAUNCH("three_interpolate_grad", bytes, 0, three_interpolate_grad_global_kernel, dim3(grid_for(total)), dim3(kBlock), s,
                    dout, out_stride, out_offset, idx, w, N, S, D, dpoints2, total);
@@ -666,10 +700,30 @@ static int tig_run(const float* dout, int64_t out_stride, int64_t out_offset, co
     // sum over destinations of ceil(len / 64) <= rows / 64 + B*S: wavefronts beyond the real chunk count exit at once
     const long long waves = rows / TIG_CHUNK + BS + 1;
     if (waves > 0x7FFFFFFFLL / 64) return PN2_E_BADARG;
-    PN2_LAUNCH("three_interpolate_grad", bytes, 0, tig_reduce_kernel, dim3((unsigned)pn2::ceil_div(waves, kBlock / 64)), dim3(kBlock),
-               s, dout, out_stride, out_offset, idx, w, (const int*)offs, (const int*)coffs, (const int*)list, BS, S, D, dpoints2);
+    SegTable st{};
+    st.nseg = 1;
+    if (dy) {
+        st.nseg = dy->nseg > 1 ? dy->nseg : 1;
+        for (int i = 0; i <= st.nseg && dy->nseg > 1; ++i) st.row_off[i] = dy->row_off[i];
+        const TigDy td{dy->y, dy->coef, dy->relu};
+        PN2_LAUNCH("three_interpolate_grad", bytes, 0, (tig_reduce_kernel<true>), dim3((unsigned)pn2::ceil_div(waves, kBlock / 64)),
+                   dim3(kBlock), s, dout, out_stride, out_offset, idx, w, (const int*)offs, (const int*)coffs, (const int*)list, BS,
+                   S, D, dpoints2, td, st);
+    } else {
+        PN2_LAUNCH("three_interpolate_grad", bytes, 0, (tig_reduce_kernel<false>), dim3((unsigned)pn2::ceil_div(waves, kBlock / 64)),
+                   dim3(kBlock), s, dout, out_stride, out_offset, idx, w, (const int*)offs, (const int*)coffs, (const int*)list, BS,
+                   S, D, dpoints2, TigDy{nullptr, nullptr, 0}, st);
+    }
     PN2_LAUNCH_CHECK();
     return 0;
+}
+
+size_t pn2::interp::grad_workspace_bytes(int B, long long rows, int S) { return tig_workspace(B, rows, S); }
+int pn2::interp::grad(const float* dout, int64_t out_stride, int64_t out_offset, const int32_t* idx, const float* w, int B, int N,
+                      int S, int D, float* dpoints2, void* workspace, size_t workspace_bytes, hipStream_t stream, const int* coff,
+                      long long rows, const DySource* dy) {
+    return tig_run(dout, out_stride, out_offset, idx, w, B, N, S, D, dpoints2, workspace, workspace_bytes, (void*)stream, coff,
+                   rows, dy);
 }
 
 extern "C" int pn2_three_interpolate_grad_f32(const float* dout, int64_t out_stride, int64_t out_offset,

@@ -385,6 +385,117 @@ class LazyRows:
         return self.y.shape
 
 
+class _InterpBNFn(torch.autograd.Function):
+    """forward(q [B,S,C], idx32 [B,N,3], w [B,N,3], gamma, beta, meta) -> (y [B*N,C] pre-BatchNorm rows, stats): the rows of a
+    feature-propagation level whose first convolution was applied to the SAMPLED rows (conv(interp(P)) = interp(conv(P)),
+    include/pn2_hip.h "first convolution HOISTED"), interpolated and given their train-mode BatchNorm statistics by one
+    launch.  The pair is a LazyRows: the next chain links to it; what comes back is the gradient with respect to
+    relu(bn(y)), and the backward scatters dZ(dout, y) to dq without storing it."""
+
+    @staticmethod
+    def forward(ctx, q, idx32, w, gamma, beta, bias, meta):
+        # (bias: the hoisted conv's bias, already inside q -- here only so that it gets the exactly zero gradient a bias in
+        # front of a train-mode BatchNorm has, instead of the rounding noise of summing dq)
+        _hip.require_device(q)
+        lib = _hip.lib()
+        from . import ops
+        B, S, C = q.shape
+        N = idx32.shape[1]
+        rows, dev = B * N, q.device
+        q = _hip.f32(q).contiguous()
+        seg_ptr, seg_keep = _hip.segments_arg(meta.get("seg_off"))
+        nseg = 1 if seg_ptr is None else len(meta["seg_off"]) - 1
+        y = torch.empty(rows, C, dtype=torch.float32, device=dev)
+        st = torch.empty(8 * nseg, C, dtype=torch.float32, device=dev)
+        L = _hip.MLPLayer()
+        L.cin = L.cout = C
+        L.has_bn, L.relu = 1, int(meta["relu"])
+        L.gamma, L.beta = _hip.ptr(gamma), _hip.ptr(beta)
+        L.running_mean, L.running_var = _hip.ptr(meta["running_mean"]), _hip.ptr(meta["running_var"])
+        L.eps, L.momentum = meta["eps"], meta["momentum"]
+        L.y, L.stats = y.data_ptr(), st.data_ptr()
+        ws = torch.empty(lib.pn2_interp_bn_workspace_bytes(B, N, S, C, nseg), dtype=torch.uint8, device=dev)
+        _hip.call("interp_bn_fwd", lib.pn2_interp_bn_fwd_f32, q.data_ptr(), idx32.data_ptr(), w.data_ptr(), B, N, S,
+                  ctypes.byref(L), seg_ptr, ops.status_word(dev).data_ptr(), ws.data_ptr(), ws.numel(), _hip.stream_ptr(),
+                  nbytes=rows * (36 + 4 * C) + 4 * B * S * C)
+        ctx.save_for_backward(idx32, w, y, st, gamma, beta, bias)
+        ctx.meta, ctx.layer, ctx.dims = meta, L, (B, N, S, C, nseg)
+        ctx.mark_non_differentiable(st)
+        return y, st
+
+    @staticmethod
+    def backward(ctx, dout, _):
+        lib = _hip.lib()
+        idx32, w, y, st, gamma, beta, bias = ctx.saved_tensors
+        B, N, S, C, nseg = ctx.dims
+        meta, L, dev = ctx.meta, ctx.layer, dout.device
+        dout = _hip.f32(dout).contiguous()
+        leaves = meta.get("leaves", (None, None, None))
+        tg, dg = _grad_target(leaves[0], gamma, ctx.needs_input_grad[3], dev)
+        tbe, dbe = _grad_target(leaves[1], beta, ctx.needs_input_grad[4], dev)
+        _, dbias = _grad_target(leaves[2], bias, bias is not None and ctx.needs_input_grad[5], dev)   # zeros
+        L.dgamma, L.dbeta = _hip.ptr(tg), _hip.ptr(tbe)
+        handed = meta["lazy_handle"].pop("partial", None)      # the linked consumer did the BatchNorm-backward sums
+        if handed is not None:
+            L.out_partial, L.out_partial_rows, L.out_partial_cpb = handed[0].data_ptr(), handed[1], handed[2]
+        else:
+            L.out_partial = None
+        dq = torch.empty(B, S, C, dtype=torch.float32, device=dev)
+        seg_ptr, seg_keep = _hip.segments_arg(meta.get("seg_off"))
+        ws = torch.empty(lib.pn2_interp_bn_workspace_bytes(B, N, S, C, nseg), dtype=torch.uint8, device=dev)
+        _hip.call("interp_bn_bwd", lib.pn2_interp_bn_bwd_f32, dout.data_ptr(), idx32.data_ptr(), w.data_ptr(), B, N, S,
+                  ctypes.byref(L), dq.data_ptr(), seg_ptr, ws.data_ptr(), ws.numel(), _hip.stream_ptr(),
+                  nbytes=B * N * (36 + 8 * C) + 4 * B * S * C)
+        return dq, None, None, dg, dbe, dbias, None
+
+
+HOIST_WIDTHS = (64, 128, 256)
+
+
+def interp_bn_rows(q, idx32, w, bn, relu=True, seg_off=None, bias=None):
+    """q [B,S,C] = the level's first conv applied to the sampled rows; idx32 / w: three_nn of the dense points ->
+    LazyRows of relu(bn(interp(q))) over the B*N dense rows (train-mode `bn`, C in HOIST_WIDTHS); see _InterpBNFn.
+    bias: that conv's bias parameter when q was computed with a DETACHED copy of it (hoisted_conv): it gets a zero gradient."""
+    bump = []
+    meta = {"relu": bool(relu), "eps": float(bn.eps), "momentum": _bn_momentum(bn, bump), "running_mean": None,
+            "running_var": None, "leaves": (bn.weight, bn.bias, bias), "lazy_handle": {}}
+    if bn.track_running_stats and bn.running_mean is not None:
+        meta["running_mean"], meta["running_var"] = bn.running_mean, bn.running_var
+    nseg = 1
+    if seg_off is not None and len(seg_off) > 2:
+        if bn.momentum is None:
+            raise NotImplementedError("row segments with cumulative-average BatchNorm (momentum=None)")
+        meta["seg_off"] = [int(v) for v in seg_off]
+        nseg = len(seg_off) - 1
+    if bump:
+        if batched_counters.active is not None:
+            batched_counters.active.pending += [(t, nseg) for t in bump]
+        else:
+            torch._foreach_add_(bump, nseg)
+    y, st = _InterpBNFn.apply(q, idx32, w, bn.weight, bn.bias, bias, meta)
+    return LazyRows(y, st, bool(relu), meta.get("seg_off"), meta["lazy_handle"])
+
+
+class _BareConv:
+    """(weight, detached bias) of a conv module in the shape chain_rows expects of a layer's conv."""
+
+    def __init__(self, conv):
+        self.weight, self.out_channels = conv.weight, conv.out_channels
+        self.bias = None if conv.bias is None else conv.bias.detach()
+
+
+def hoisted_conv(rows, conv):
+    """rows [R, C_in] -> conv(rows) [R, C_out], the bias applied but outside the graph (interp_bn_rows gives it its gradient)."""
+    return chain_rows(rows, [(_BareConv(conv), None, False)])
+
+
+def hoist_ok(conv, bn, n_layers, device):
+    """May a feature-propagation level without a skip connection run its first conv in front of the interpolation?"""
+    return (n_layers >= 2 and device.type == "cuda" and GEMM_PRECISION == "f32" and bn is not None and bn.training
+            and conv.out_channels in HOIST_WIDTHS and not os.environ.get("PN2_NO_HOIST")
+            and not os.environ.get("PN2_NO_LAZY_ROWS"))
+
+
 def _chain_spec(layers, pool_k, seg_off, dx_first_col):
     """(meta, params) of a chain call, or None for an empty chain; bumps num_batches_tracked."""
     layers = list(layers)

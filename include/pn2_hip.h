@@ -31,7 +31,7 @@ extern "C" {
 #define PN2_E_BADARG (-1)   /* null pointer / non-positive size / unsupported size */
 #define PN2_E_WORKSPACE (-2) /* workspace too small */
 
-#define PN2_ABI_VERSION 4
+#define PN2_ABI_VERSION 5
 
 /* Bits of the caller-owned sticky STATUS word (a device int32 the caller zeroes once and reads at a synchronisation
  * point it has anyway, e.g. the loss read-back; the Python mirror: ops.check_status()).  A kernel ORs a bit in when it
@@ -410,6 +410,34 @@ int pn2_mlp_chain_bwd_f32(const float *x, int64_t ldx, int rows, const pn2_mlp_l
                           size_t workspace_bytes, void *stream);
 size_t pn2_mlp_link_partial_bytes(int rows, int cin, int nseg, int32_t *block_rows, int32_t *chunks_per_block);
 int pn2_mlp_reduce_wgrad(const pn2_wgrad_task *tasks, int n, void *stream);
+
+/* Feature propagation with the first convolution HOISTED in front of the interpolation   (blocks.py:194-215)
+ *
+ * Where a feature-propagation level has no skip connection (fp1: points1 = None, PointNet2.py:156) its first layer is
+ * conv(interp(P)) with P the [B,S,D2] sampled rows.  Interpolation is linear and its three weights sum to one, so
+ *     conv(interp(P)) = interp(conv(P)):
+ * the contraction runs over the B*S sampled rows (a chain call of one bare conv layer, bias included) instead of the B*N
+ * dense rows -- at the headline shape 1024 rows instead of 262 144 -- and what is left at full resolution is the
+ * interpolation itself, which these two entry points fuse with the layer's train-mode BatchNorm:
+ *
+ * pn2_interp_bn_fwd_f32   y[r][:] = (q[i0]*w0 + q[i1]*w1) + q[i2]*w2 (the reference's operation order), the per-chunk
+ *   (mean, M2) statistics partials from the same registers, then the finalize of the chain kernels: layer->stats gets the
+ *   coefficient block(s), the running statistics advance.  q: [B][S][C] rows, idx / w: [B*N][3] (three_nn), layer: cout = C
+ *   (64, 128 or 256), has_bn = 1, gamma .. momentum, y [B*N][C], stats [nseg][8][C].  The result is exactly a chain's
+ *   PN2_CHAIN_LAZY_OUT output: the next chain links to (y, stats) through layers[0].in_stats.
+ * pn2_interp_bn_bwd_f32   dout = gradient with respect to relu(bn(y)) (what the linked consumer's dgrad leaves; its
+ *   BatchNorm-backward sums through layer->out_partial as between linked chains, NULL: reduced here).  Finalizes dgamma /
+ *   dbeta (accumulated) and the backward coefficients, then scatters dZ(dout, y) -- rebuilt while the rows are read, never
+ *   stored -- to dq [B][S][C] with the bucketed reduction of pn2_three_interpolate_grad_f32.
+ * Rounding: the same products summed in another order (~1e-7 relative); `segments` as for the chains (whole clouds per
+ * segment).  workspace: pn2_interp_bn_workspace_bytes() for either direction. */
+size_t pn2_interp_bn_workspace_bytes(int B, int N, int S, int C, int nseg);
+int pn2_interp_bn_fwd_f32(const float *q, const int32_t *idx, const float *w, int B, int N, int S,
+                          const pn2_mlp_layer *layer, const pn2_segments *segments, int32_t *status, void *workspace,
+                          size_t workspace_bytes, void *stream);
+int pn2_interp_bn_bwd_f32(const float *dout, const int32_t *idx, const float *w, int B, int N, int S,
+                          const pn2_mlp_layer *layer, float *dq, const pn2_segments *segments, void *workspace,
+                          size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * PointTransformerV3 serialized patch attention   replaces Modules/PointTransformerV3/blocks.py:384-437 and :457-488
