@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..mlp import chain_rows, hoist_ok, hoisted_conv, interp_bn_rows
+from ..mlp import chain_rows, group_bn_rows, group_hoist_ok, hoist_ok, hoisted_conv, interp_bn_rows
 from .pointnet2_utils import *  # noqa: F401,F403  (the reference re-exports the L0 ops from here)
 from .pointnet2_utils import _sample_and_group_i32, _draw_start
 
@@ -90,6 +90,14 @@ def _group_mlp_max(grouped, convs, bns, seg_off=None, coords_first=0):
     return y.view(B, S, -1)
 
 
+def _hoisted_group_mlp_max(xyz_t, new_xyz, pts_t, idx, convs, bns, xyz_last, seg_off=None):
+    """_group_mlp_max of the grouped rows [xyz[idx] - centre, pts[idx]] without forming them -> [B,S,C_out]."""
+    B, S, K = idx.shape
+    first = group_bn_rows(xyz_t, new_xyz, pts_t, idx, convs[0], bns[0], xyz_last=xyz_last, seg_off=seg_off)
+    y = chain_rows(first, [(c, b, True) for c, b in zip(convs[1:], bns[1:])], pool_k=K, seg_off=seg_off)
+    return y.view(B, S, -1)
+
+
 class PointNetSetAbstraction(nn.Module):
     def __init__(self, npoint, radius, nsample, in_channel, mlp, group_all):
         super().__init__()
@@ -108,6 +116,15 @@ class PointNetSetAbstraction(nn.Module):
         if self.group_all:
             new_xyz, grouped = sample_and_group_all(xyz_t, pts_t)
         else:
+            B, N, _ = xyz_t.shape
+            D = 0 if pts_t is None else pts_t.shape[2]
+            if group_hoist_ok(self.mlp_convs[0], self.mlp_bns[0], len(self.mlp_convs), B, N, self.npoint, min(self.nsample, N), D,
+                              xyz_t.device):
+                # the feature share of the first conv runs on the N source points, not on the S*K grouped rows (mlp.group_bn_rows)
+                _, new_xyz = ops.furthest_point_sample(xyz_t, self.npoint, _draw_start(B, N, xyz_t.device))
+                idx = ops.ball_query(self.radius, self.nsample, xyz_t, new_xyz)
+                pooled = _hoisted_group_mlp_max(xyz_t, new_xyz, pts_t, idx, self.mlp_convs, self.mlp_bns, False)
+                return new_xyz.permute(0, 2, 1), pooled.permute(0, 2, 1)
             new_xyz, grouped, _, _ = _sample_and_group_i32(self.npoint, self.radius, self.nsample, xyz_t, pts_t)
         # [xyz - centroid, feats]: the 3 leading channels need no gradient (GroupPoints differentiates the features only)
         pooled = _group_mlp_max(grouped, self.mlp_convs, self.mlp_bns, coords_first=0 if self.group_all or pts_t is None else 3)
@@ -139,6 +156,10 @@ class PointNetSetAbstractionMsg(nn.Module):
         scales = []
         for radius, K, convs, bns in zip(self.radius_list, self.nsample_list, self.conv_blocks, self.bn_blocks):
             idx = ops.ball_query(radius, K, xyz_t, new_xyz)
+            if pts_t is not None and group_hoist_ok(convs[0], bns[0], len(convs), B, N, idx.shape[1], idx.shape[2], pts_t.shape[2],
+                                                    xyz_t.device):
+                scales.append(_hoisted_group_mlp_max(xyz_t, new_xyz, pts_t, idx, convs, bns, True))
+                continue
             grouped = ops.GroupPoints.apply(xyz_t, new_xyz, pts_t, idx, True)
             scales.append(_group_mlp_max(grouped, convs, bns))
         return new_xyz.permute(0, 2, 1), torch.cat(scales, dim=-1).permute(0, 2, 1)

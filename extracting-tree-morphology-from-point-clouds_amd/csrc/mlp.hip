@@ -1803,16 +1803,83 @@ extern "C" int pn2_mlp_reduce_wgrad(const pn2_wgrad_task* tasks, int n, void* st
 namespace {
 
 constexpr int IB_PASSES = 8;
-inline int interp_block_rows(int C) { return 2 * IB_PASSES * (256 / (C / 4)); }   // 256 / 128 / 64 rows at C = 64 / 128 / 256
+inline int interp_block_rows(int C) { return 2 * IB_PASSES * (256 / (C / 4)); }   // 512 / 256 / 128 / 64 rows at C = 32 / 64 / 128 / 256
 
-__global__ __launch_bounds__(256) void interp_stats_kernel(const float* __restrict__ q, const int32_t* __restrict__ idx,
-                                                           const float* __restrict__ w, int N, int S, int C,
-                                                           float* __restrict__ y, float* __restrict__ partial, long long pchunk,
-                                                           long long pcol, long long pwhich, const SegTable st, int32_t* status) {
+__device__ __forceinline__ int checked_index(int j, int n, int32_t* status) {
+    if ((unsigned)j < (unsigned)n) return j;
+    if (status) atomicOr(status, PN2_STATUS_BAD_INDEX);   // untrusted index: row 0 instead, and say so
+    return 0;
+}
+
+// Where a row of the layer comes from.  InterpSrc: the three-neighbour interpolation of the sampled rows q (feature
+// propagation).  GroupSrc: a grouped row (b, s, k) of a set-abstraction level, gf[b][idx] + Wx (xyz[b][idx] - new_xyz[b][s]) --
+// the features' share of the first conv was applied to the SOURCE points (gf, bias included), the centred coordinates'
+// share (three multiply-adds per channel, the same centred differences the reference forms) is added here.
+struct InterpSrc {
+    const float* q;
+    const int32_t* idx;
+    const float* w;
+    const int32_t* row_cloud;
+    int N, S;
+    __device__ __forceinline__ void init(int, int) {}
+    __device__ __forceinline__ float4 row(int row, int c, int C, int32_t* status) const {
+        const long long r3 = 3ll * row;
+        const int j0 = checked_index(idx[r3], S, status), j1 = checked_index(idx[r3 + 1], S, status),
+                  j2 = checked_index(idx[r3 + 2], S, status);
+        const float w0 = w[r3], w1 = w[r3 + 1], w2 = w[r3 + 2];
+        const float* qb = q + (long long)(row_cloud ? row_cloud[row] : row / N) * S * C + c;
+        const float4 a = *(const float4*)(qb + (long long)j0 * C);
+        const float4 b = *(const float4*)(qb + (long long)j1 * C);
+        const float4 d = *(const float4*)(qb + (long long)j2 * C);
+        // the reference's order (blocks.py:204): (p0*w0 + p1*w1) + p2*w2, separate multiplies and adds
+        float4 v;
+        v.x = __fadd_rn(__fadd_rn(__fmul_rn(a.x, w0), __fmul_rn(b.x, w1)), __fmul_rn(d.x, w2));
+        v.y = __fadd_rn(__fadd_rn(__fmul_rn(a.y, w0), __fmul_rn(b.y, w1)), __fmul_rn(d.y, w2));
+        v.z = __fadd_rn(__fadd_rn(__fmul_rn(a.z, w0), __fmul_rn(b.z, w1)), __fmul_rn(d.z, w2));
+        v.w = __fadd_rn(__fadd_rn(__fmul_rn(a.w, w0), __fmul_rn(b.w, w1)), __fmul_rn(d.w, w2));
+        return v;
+    }
+};
+struct GroupSrc {
+    const float* gf;       // [B][N][C]
+    const float* xyz;      // source coordinates, element (b, n, d) at b*sb + n*sn + d*sc
+    long long sb, sn, sc;
+    const float* new_xyz;  // [B*S][3]
+    const float* wx;       // coordinate columns of the conv weight: wx[c * ldw + d]
+    long long ldw;
+    const int32_t* idx;    // [B*S*K] cloud-local
+    int N, S, K;
+    float k[4][3];         // the thread's four channels
+    __device__ __forceinline__ void init(int c, int) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) k[j][d] = wx[(long long)(c + j) * ldw + d];
+    }
+    __device__ __forceinline__ float4 row(int row, int c, int C, int32_t* status) const {
+        const int bs = row / K, b = bs / S;
+        const int j = checked_index(idx[row], N, status);
+        const float* px = xyz + (long long)b * sb + (long long)j * sn;
+        const float* pc = new_xyz + 3ll * bs;
+        const float dx = __fsub_rn(px[0], pc[0]), dy = __fsub_rn(px[sc], pc[1]), dz = __fsub_rn(px[2 * sc], pc[2]);
+        float4 v = *(const float4*)(gf + ((long long)b * N + j) * C + c);
+        v.x += __builtin_fmaf(k[0][2], dz, __builtin_fmaf(k[0][1], dy, k[0][0] * dx));
+        v.y += __builtin_fmaf(k[1][2], dz, __builtin_fmaf(k[1][1], dy, k[1][0] * dx));
+        v.z += __builtin_fmaf(k[2][2], dz, __builtin_fmaf(k[2][1], dy, k[2][0] * dx));
+        v.w += __builtin_fmaf(k[3][2], dz, __builtin_fmaf(k[3][1], dy, k[3][0] * dx));
+        return v;
+    }
+};
+
+template <class SRC>
+__global__ __launch_bounds__(256) void rows_stats_kernel(SRC src, int C, float* __restrict__ y, float* __restrict__ partial,
+                                                         long long pchunk, long long pcol, long long pwhich, const SegTable st,
+                                                         int32_t* status) {
     __shared__ float red[1024];    // [rows per pass][C]
     __shared__ float smean[256];
     const int tpr = C / 4, rpp = 256 / tpr, ch = IB_PASSES * rpp;
     const int cg = threadIdx.x % tpr, rs = threadIdx.x / tpr, c = 4 * cg;
+    src.init(c, C);
     const RowBlock rb = row_block(st, (int)blockIdx.x, 2 * ch);
     for (int h = 0; h < 2; ++h) {
         const int base = rb.row0 + h * ch;
@@ -1824,24 +1891,7 @@ __global__ __launch_bounds__(256) void interp_stats_kernel(const float* __restri
             const int row = base + p * rpp + rs;
             v[p] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (row < rb.row_end) {
-                const long long r3 = 3ll * row;
-                int j0 = idx[r3], j1 = idx[r3 + 1], j2 = idx[r3 + 2];
-                if (((unsigned)j0 >= (unsigned)S) | ((unsigned)j1 >= (unsigned)S) | ((unsigned)j2 >= (unsigned)S)) {
-                    if (status) atomicOr(status, PN2_STATUS_BAD_INDEX);   // untrusted index: row 0 instead, and say so
-                    j0 = (unsigned)j0 < (unsigned)S ? j0 : 0;
-                    j1 = (unsigned)j1 < (unsigned)S ? j1 : 0;
-                    j2 = (unsigned)j2 < (unsigned)S ? j2 : 0;
-                }
-                const float w0 = w[r3], w1 = w[r3 + 1], w2 = w[r3 + 2];
-                const float* qb = q + (long long)(row / N) * S * C + c;
-                const float4 a = *(const float4*)(qb + (long long)j0 * C);
-                const float4 b = *(const float4*)(qb + (long long)j1 * C);
-                const float4 d = *(const float4*)(qb + (long long)j2 * C);
-                // the reference's order (blocks.py:204): (p0*w0 + p1*w1) + p2*w2, separate multiplies and adds
-                v[p].x = __fadd_rn(__fadd_rn(__fmul_rn(a.x, w0), __fmul_rn(b.x, w1)), __fmul_rn(d.x, w2));
-                v[p].y = __fadd_rn(__fadd_rn(__fmul_rn(a.y, w0), __fmul_rn(b.y, w1)), __fmul_rn(d.y, w2));
-                v[p].z = __fadd_rn(__fadd_rn(__fmul_rn(a.z, w0), __fmul_rn(b.z, w1)), __fmul_rn(d.z, w2));
-                v[p].w = __fadd_rn(__fadd_rn(__fmul_rn(a.w, w0), __fmul_rn(b.w, w1)), __fmul_rn(d.w, w2));
+                v[p] = src.row(row, c, C, status);
                 *(float4*)(y + (long long)row * C + c) = v[p];
             }
         }
@@ -1888,33 +1938,37 @@ __global__ __launch_bounds__(256) void interp_stats_kernel(const float* __restri
     }
 }
 
-bool interp_bn_args_ok(const void* idx, const void* w, int B, int N, int S, const pn2_mlp_layer* L, const pn2_segments* sg) {
-    if (!idx || !w || !L || B <= 0 || N <= 0 || S <= 0 || (long long)B * N >= (1ll << 31) / 4) return false;
+bool interp_bn_args_ok(const void* idx, const void* w, const int32_t* coff, int B, int N, int S, long long rows,
+                       const pn2_mlp_layer* L, const pn2_segments* sg) {
+    if (!idx || !w || !L || B <= 0 || N <= 0 || S <= 0 || rows <= 0 || rows >= (1ll << 31) / 4 || B > 65535 || S > 8192) return false;
+    if (!coff && rows != (long long)B * N) return false;
     if (!(L->cout == 64 || L->cout == 128 || L->cout == 256) || !L->has_bn || !L->y || !L->stats || !aligned16(L->y)) return false;
-    if (!segs_valid(B * N, sg, 1)) return false;
-    for (int i = 0; sg && sg->nseg > 1 && i <= sg->nseg; ++i)
-        if (sg->row_off[i] % N) return false;   // whole clouds per segment
+    if (!segs_valid((int)rows, sg, 1)) return false;
+    for (int i = 0; !coff && sg && sg->nseg > 1 && i <= sg->nseg; ++i)
+        if (sg->row_off[i] % N) return false;   // whole clouds per segment (ragged clouds: the caller's promise)
     return true;
 }
 
 }  // namespace
 
-extern "C" size_t pn2_interp_bn_workspace_bytes(int B, int N, int S, int C, int nseg) {
-    if (B <= 0 || N <= 0 || S <= 0 || C <= 0) return 0;
+extern "C" size_t pn2_interp_bn_workspace_bytes(int B, long long rows, int S, int C, int nseg) {
+    if (B <= 0 || rows <= 0 || S <= 0 || C <= 0) return 0;
     if (nseg < 1) nseg = 1;
-    const long long rows = (long long)B * N;
     const size_t part = ((size_t)pn2::ceil_div(rows, 32) + 2 * (size_t)nseg) * 2 * (size_t)C * sizeof(float);
     return slice_region_bytes((int)rows, nseg, (size_t)C) + align256(part) + align256(pn2::interp::grad_workspace_bytes(B, rows, S));
 }
 
-extern "C" int pn2_interp_bn_fwd_f32(const float* q, const int32_t* idx, const float* w, int B, int N, int S,
-                                     const pn2_mlp_layer* layer, const pn2_segments* segments, int32_t* status, void* workspace,
-                                     size_t workspace_bytes, void* stream) {
-    if (!q || !aligned16(q) || !interp_bn_args_ok(idx, w, B, N, S, layer, segments)) return PN2_E_BADARG;
+extern "C" int pn2_interp_bn_fwd_f32(const float* q, const int32_t* idx, const float* w, const int32_t* coff,
+                                     const int32_t* row_cloud, int B, int N, int S, long long nrows, const pn2_mlp_layer* layer,
+                                     const pn2_segments* segments, int32_t* status, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+    if (!q || !aligned16(q) || (coff == nullptr) != (row_cloud == nullptr) ||
+        !interp_bn_args_ok(idx, w, coff, B, N, S, nrows, layer, segments))
+        return PN2_E_BADARG;
     const pn2_mlp_layer& L = *layer;
-    const int rows = B * N, C = L.cout;
+    const int rows = (int)nrows, C = L.cout;
     const Segs Sg = make_segs(rows, segments);
-    if (!workspace || workspace_bytes < pn2_interp_bn_workspace_bytes(B, N, S, C, Sg.nseg)) return PN2_E_WORKSPACE;
+    if (!workspace || workspace_bytes < pn2_interp_bn_workspace_bytes(B, rows, S, C, Sg.nseg)) return PN2_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     const FinScratch fs = fin_scratch(workspace, Sg.nseg, (size_t)C);
     float* part = (float*)((char*)workspace + slice_region_bytes(rows, Sg.nseg, (size_t)C));
@@ -1922,20 +1976,22 @@ extern "C" int pn2_interp_bn_fwd_f32(const float* q, const int32_t* idx, const f
     int nblk = 0;
     const SegTable st = make_table(Sg, R, &nblk);
     const long long cm = cm_stride(rows, R, Sg.nseg);
-    PN2_LAUNCH("interp_bn_fwd", (double)rows * (36.0 + 4.0 * C) + 4.0 * B * S * C, 0, interp_stats_kernel, dim3(nblk), dim3(256), s,
-               q, idx, w, N, S, C, L.y, part, cm ? 2ll : 2ll * C, cm ? cm : 1ll, cm ? 1ll : (long long)C, st, status);
+    const InterpSrc src{q, idx, w, row_cloud, N, S};
+    PN2_LAUNCH("interp_bn_fwd", (double)rows * (36.0 + 4.0 * C) + 4.0 * B * S * C, 0, (rows_stats_kernel<InterpSrc>), dim3(nblk),
+               dim3(256), s, src, C, L.y, part, cm ? 2ll : 2ll * C, cm ? cm : 1ll, cm ? 1ll : (long long)C, st, status);
     PN2_LAUNCH_CHECK();
     return launch_bn_finalize(part, fs, Sg, R, rows, L, s, cm);
 }
 
-extern "C" int pn2_interp_bn_bwd_f32(const float* dout, const int32_t* idx, const float* w, int B, int N, int S,
-                                     const pn2_mlp_layer* layer, float* dq, const pn2_segments* segments, void* workspace,
-                                     size_t workspace_bytes, void* stream) {
-    if (!dout || !dq || !aligned16(dout) || !interp_bn_args_ok(idx, w, B, N, S, layer, segments)) return PN2_E_BADARG;
+extern "C" int pn2_interp_bn_bwd_f32(const float* dout, const int32_t* idx, const float* w, const int32_t* coff, int B, int N,
+                                     int S, long long nrows, const pn2_mlp_layer* layer, float* dq, const pn2_segments* segments,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+    // (the scatter finds a row's cloud through its destination: no row -> cloud table on this side)
+    if (!dout || !dq || !aligned16(dout) || !interp_bn_args_ok(idx, w, coff, B, N, S, nrows, layer, segments)) return PN2_E_BADARG;
     const pn2_mlp_layer& L = *layer;
-    const int rows = B * N, C = L.cout;
+    const int rows = (int)nrows, C = L.cout;
     const Segs Sg = make_segs(rows, segments);
-    if (!workspace || workspace_bytes < pn2_interp_bn_workspace_bytes(B, N, S, C, Sg.nseg)) return PN2_E_WORKSPACE;
+    if (!workspace || workspace_bytes < pn2_interp_bn_workspace_bytes(B, rows, S, C, Sg.nseg)) return PN2_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     const FinScratch fs = fin_scratch(workspace, Sg.nseg, (size_t)C);
     char* base = (char*)workspace + slice_region_bytes(rows, Sg.nseg, (size_t)C);
@@ -1961,6 +2017,214 @@ extern "C" int pn2_interp_bn_bwd_f32(const float* dout, const int32_t* idx, cons
     if ((st_ = launch_bn_bwd_finalize(partial, fs, Sg, R, cpb, rows, L, s, cm))) return st_;
     int32_t one[2] = {0, rows};
     const pn2::interp::DySource dy{L.y, L.stats, L.relu, Sg.nseg, Sg.nseg > 1 ? Sg.row_off : one};
-    return pn2::interp::grad(dout, C, 0, idx, w, B, N, S, C, dq, base + part_bytes, workspace_bytes - (size_t)(base + part_bytes - (char*)workspace),
-                             s, nullptr, rows, &dy);
+    char* tws = base + part_bytes;
+    return pn2::interp::grad(dout, C, 0, idx, w, B, N, S, C, dq, tws, workspace_bytes - (size_t)(tws - (char*)workspace), s,
+                             (const int*)coff, rows, &dy);
+}
+
+// ================================================================== set abstraction, first convolution hoisted
+// (pn2_hip.h "Set abstraction with the first convolution HOISTED").  Forward: rows_stats_kernel<GroupSrc>.  Backward: one
+// wavefront per group, lanes across the channels (the layout of group.hip's group_grad_groups_kernel): dZ is rebuilt from
+// (dA, Z) row by row; the rows that go where row 0 goes -- the padding of a sparse ball -- are summed in registers and leave as
+// one atomic per channel, the others as one atomic each; the coordinate weights' gradient sum_k dZ[k][c] * (xyz_k - centre)
+// accumulates in registers over all the groups a wavefront walks and leaves as one partial per workgroup.
+namespace {
+
+constexpr int GB_BLOCKS = 1024;   // workgroups of the backward scatter (= partials of the coordinate-weight gradient)
+
+__global__ __launch_bounds__(256) void group_dy_scatter_kernel(const float* __restrict__ dout, const float* __restrict__ z,
+                                                               const float* __restrict__ coef_all, int relu,
+                                                               const float* __restrict__ xyz, long long sb, long long sn,
+                                                               long long sc, const float* __restrict__ new_xyz,
+                                                               const int32_t* __restrict__ idx, long long groups, int N, int S,
+                                                               int K, int C, float* __restrict__ dgf,
+                                                               float* __restrict__ wpart, const SegTable st) {
+    __shared__ float red[4][3][256];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float aw[4][3];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) aw[q][0] = aw[q][1] = aw[q][2] = 0.0f;
+    for (long long g = (long long)blockIdx.x * 4 + wv; g < groups; g += (long long)gridDim.x * 4) {
+        const long long r0 = g * K;
+        const int b = (int)(g / S);
+        const float* coef = coef_all + (st.nseg > 1 ? (long long)seg_of_row(st, (int)r0) * ST_ROWS * C : 0);
+        const int mine = lane < K ? idx[r0 + lane] : -1;
+        const bool ok = (unsigned)mine < (unsigned)N;           // (a bad index was flagged by the forward pass)
+        float dx = 0.0f, dy = 0.0f, dz = 0.0f;                  // lane k: centred coordinates of row k
+        if (ok) {
+            const float* px = xyz + (long long)b * sb + (long long)mine * sn;
+            const float* pc = new_xyz + 3ll * g;
+            dx = __fsub_rn(px[0], pc[0]), dy = __fsub_rn(px[sc], pc[1]), dz = __fsub_rn(px[2 * sc], pc[2]);
+        }
+        const int j0 = __builtin_amdgcn_readfirstlane(mine);
+        const unsigned long long same = __ballot(lane < K && ok && mine == j0);
+        const unsigned long long other = __ballot(lane < K && ok && mine != j0);
+        float* dst = dgf + (long long)b * N * C;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (64 * q >= C) break;                              // uniform
+            const bool live = 64 * q + lane < C;                 // (C = 32: half a wavefront)
+            const int c = live ? 64 * q + lane : C - 1;
+            const float km = coef[ST_MEAN * C + c], ks = coef[ST_SCALE * C + c], kb = coef[ST_BETA * C + c];
+            const float ka = coef[ST_A * C + c], kq = coef[ST_B * C + c];
+            float acc = 0.0f;
+            for (int pass = 0; pass < 2; ++pass) {
+                unsigned long long m = pass ? other : same;
+                while (m) {   // wave-uniform; four rows in flight
+                    int k[4];
+                    float dv[4], zv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        k[u] = m ? (int)__builtin_ctzll(m) : -1;
+                        if (m) m &= m - 1ull;
+                        const long long r = r0 + (k[u] >= 0 ? k[u] : 0);
+                        dv[u] = dout[r * C + c];
+                        zv[u] = z[r * C + c];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (k[u] < 0) break;                     // uniform
+                        const float t = __builtin_fmaf(zv[u] - km, ks, kb);
+                        const float gm = (!relu || t > 0.0f) ? dv[u] : 0.0f;
+                        const float d = live ? ks * (gm - ka - (zv[u] - km) * kq) : 0.0f;
+                        aw[q][0] += d * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dx), k[u]));
+                        aw[q][1] += d * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dy), k[u]));
+                        aw[q][2] += d * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dz), k[u]));
+                        if (pass == 0)
+                            acc += d;
+                        else if (live)
+                            atomicAdd(dst + (long long)__builtin_amdgcn_readlane(mine, k[u]) * C + c, d);
+                    }
+                }
+                if (pass == 0 && same && live) atomicAdd(dst + (long long)j0 * C + c, acc);
+            }
+        }
+    }
+    // one partial of the coordinate-weight gradient per workgroup: [3][C]
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) red[wv][d][64 * q + lane] = aw[q][d];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 3 * C; e += 256) {
+        const int d = e / C, c = e - d * C;
+        wpart[(long long)blockIdx.x * 3 * C + e] = (red[0][d][c] + red[1][d][c]) + (red[2][d][c] + red[3][d][c]);
+    }
+}
+
+// dwx[c * ld + d] = sum over the scatter's workgroups, fixed order
+__global__ __launch_bounds__(256) void group_wx_reduce_kernel(const float* __restrict__ wpart, int nblk, int C,
+                                                              float* __restrict__ dwx, long long ld) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= 3 * C) return;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    int k = 0;
+    for (; k + 4 <= nblk; k += 4) {
+        a0 += wpart[(long long)k * 3 * C + e];
+        a1 += wpart[(long long)(k + 1) * 3 * C + e];
+        a2 += wpart[(long long)(k + 2) * 3 * C + e];
+        a3 += wpart[(long long)(k + 3) * 3 * C + e];
+    }
+    for (; k < nblk; ++k) a0 += wpart[(long long)k * 3 * C + e];
+    const int d = e / C, c = e - d * C;
+    dwx[(long long)c * ld + d] = (a0 + a1) + (a2 + a3);
+}
+
+bool group_bn_args_ok(const void* xyz, const void* new_xyz, const void* idx, int B, int N, int S, int K, const pn2_mlp_layer* L,
+                      const pn2_segments* sg) {
+    if (!xyz || !new_xyz || !idx || !L || B <= 0 || N <= 0 || S <= 0 || K <= 0 || K > 64) return false;
+    const long long rows = (long long)B * S * K;
+    if (rows >= (1ll << 31) / 4) return false;
+    if (!(L->cout == 32 || L->cout == 64 || L->cout == 128 || L->cout == 256) || !L->has_bn || !L->y || !L->stats || !aligned16(L->y))
+        return false;
+    if (!segs_valid((int)rows, sg, K)) return false;
+    for (int i = 0; sg && sg->nseg > 1 && i <= sg->nseg; ++i)
+        if (sg->row_off[i] % (S * K)) return false;   // whole clouds per segment
+    return true;
+}
+
+size_t group_part_bytes(long long rows, int nseg, int C) {
+    return align256(((size_t)pn2::ceil_div(rows, 32) + 2 * (size_t)nseg) * 2 * (size_t)C * sizeof(float));
+}
+
+}  // namespace
+
+extern "C" size_t pn2_group_bn_workspace_bytes(int B, int S, int K, int C, int nseg) {
+    if (B <= 0 || S <= 0 || K <= 0 || C <= 0) return 0;
+    if (nseg < 1) nseg = 1;
+    const long long rows = (long long)B * S * K;
+    return slice_region_bytes((int)rows, nseg, (size_t)C) + group_part_bytes(rows, nseg, C) +
+           align256((size_t)GB_BLOCKS * 3 * C * sizeof(float));
+}
+
+extern "C" int pn2_group_bn_fwd_f32(const float* gf, const float* xyz, int64_t sb, int64_t sn, int64_t sc, const float* new_xyz,
+                                    const int32_t* idx, const float* wx, int64_t ldw, int B, int N, int S, int K,
+                                    const pn2_mlp_layer* layer, const pn2_segments* segments, int32_t* status, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+    if (!gf || !aligned16(gf) || !wx || !group_bn_args_ok(xyz, new_xyz, idx, B, N, S, K, layer, segments)) return PN2_E_BADARG;
+    const pn2_mlp_layer& L = *layer;
+    const int rows = B * S * K, C = L.cout;
+    const Segs Sg = make_segs(rows, segments);
+    if (!workspace || workspace_bytes < pn2_group_bn_workspace_bytes(B, S, K, C, Sg.nseg)) return PN2_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const FinScratch fs = fin_scratch(workspace, Sg.nseg, (size_t)C);
+    float* part = (float*)((char*)workspace + slice_region_bytes(rows, Sg.nseg, (size_t)C));
+    const int R = interp_block_rows(C);
+    int nblk = 0;
+    const SegTable st = make_table(Sg, R, &nblk);
+    const long long cm = cm_stride(rows, R, Sg.nseg);
+    GroupSrc src{};
+    src.gf = gf, src.xyz = xyz, src.sb = sb, src.sn = sn, src.sc = sc, src.new_xyz = new_xyz, src.wx = wx, src.ldw = ldw;
+    src.idx = idx, src.N = N, src.S = S, src.K = K;
+    PN2_LAUNCH("group_bn_fwd", (double)rows * (8.0 * C + 20.0), 6.0 * rows * C, (rows_stats_kernel<GroupSrc>), dim3(nblk), dim3(256), s,
+               src, C, L.y, part, cm ? 2ll : 2ll * C, cm ? cm : 1ll, cm ? 1ll : (long long)C, st, status);
+    PN2_LAUNCH_CHECK();
+    return launch_bn_finalize(part, fs, Sg, R, rows, L, s, cm);
+}
+
+extern "C" int pn2_group_bn_bwd_f32(const float* dout, const float* xyz, int64_t sb, int64_t sn, int64_t sc, const float* new_xyz,
+                                    const int32_t* idx, int B, int N, int S, int K, const pn2_mlp_layer* layer, float* dgf,
+                                    float* dwx, int64_t lddw, const pn2_segments* segments, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+    if (!dout || !dgf || !dwx || !aligned16(dout) || !group_bn_args_ok(xyz, new_xyz, idx, B, N, S, K, layer, segments))
+        return PN2_E_BADARG;
+    const pn2_mlp_layer& L = *layer;
+    const int rows = B * S * K, C = L.cout;
+    const Segs Sg = make_segs(rows, segments);
+    if (!workspace || workspace_bytes < pn2_group_bn_workspace_bytes(B, S, K, C, Sg.nseg)) return PN2_E_WORKSPACE;
+    hipStream_t s = (hipStream_t)stream;
+    const FinScratch fs = fin_scratch(workspace, Sg.nseg, (size_t)C);
+    char* base = (char*)workspace + slice_region_bytes(rows, Sg.nseg, (size_t)C);
+    float* part = (float*)base;
+    float* wpart = (float*)(base + group_part_bytes(rows, Sg.nseg, C));
+    const float* partial = part;
+    int R = RB, cpb = 1, st_;
+    long long cm = 0;
+    if (L.out_partial) {   // BatchNorm-backward sums left behind by the linked consumer's dgrad epilogue
+        partial = L.out_partial;
+        R = L.out_partial_rows;
+        cpb = L.out_partial_cpb;
+        if (R <= 0 || cpb != 2) return PN2_E_BADARG;
+        cm = cm_stride(rows, R, Sg.nseg);
+    } else {
+        int nblk = 0;
+        const SegTable tb = make_table(Sg, RB, &nblk);
+        PN2_LAUNCH("bn_bwd_reduce", 8.0 * rows * C, 0, (bn_bwd_reduce_kernel<true>), dim3(nblk), dim3(256), s, dout, (long long)C,
+                   (const float*)L.y, (long long)C, rows, C, (const float*)L.stats, L.relu, part, tb, 0, 0);
+        PN2_LAUNCH_CHECK();
+    }
+    if ((st_ = launch_bn_bwd_finalize(partial, fs, Sg, R, cpb, rows, L, s, cm))) return st_;
+    PN2_HIP_CHECK(hipMemsetAsync(dgf, 0, (size_t)B * N * C * sizeof(float), s));
+    const long long groups = (long long)B * S;
+    int nb = (int)((groups + 3) / 4);
+    if (nb > GB_BLOCKS) nb = GB_BLOCKS;
+    int dummy = 0;
+    const SegTable st = make_table(Sg, RB, &dummy);   // (row offsets only: seg_of_row)
+    PN2_LAUNCH("group_bn_bwd", (double)rows * (8.0 * C + 20.0) + 4.0 * B * N * C, 8.0 * rows * C, group_dy_scatter_kernel, dim3(nb),
+               dim3(256), s, dout, (const float*)L.y, (const float*)L.stats, L.relu, xyz, (long long)sb, (long long)sn, (long long)sc,
+               new_xyz, idx, groups, N, S, K, C, dgf, wpart, st);
+    PN2_LAUNCH("group_bn_wx", 12.0 * nb * C, 0, group_wx_reduce_kernel, dim3(pn2::ceil_div(3 * C, 256)), dim3(256), s,
+               (const float*)wpart, nb, C, dwx, (long long)lddw);
+    PN2_LAUNCH_CHECK();
+    return 0;
 }

@@ -386,11 +386,12 @@ class LazyRows:
 
 
 class _InterpBNFn(torch.autograd.Function):
-    """forward(q [B,S,C], idx32 [B,N,3], w [B,N,3], gamma, beta, meta) -> (y [B*N,C] pre-BatchNorm rows, stats): the rows of a
-    feature-propagation level whose first convolution was applied to the SAMPLED rows (conv(interp(P)) = interp(conv(P)),
-    include/pn2_hip.h "first convolution HOISTED"), interpolated and given their train-mode BatchNorm statistics by one
-    launch.  The pair is a LazyRows: the next chain links to it; what comes back is the gradient with respect to
-    relu(bn(y)), and the backward scatters dZ(dout, y) to dq without storing it."""
+    """forward(q [B,S,C], idx32 [rows,3], w [rows,3], gamma, beta, bias, meta) -> (y [rows,C] pre-BatchNorm rows, stats): the
+    rows of a feature-propagation level whose first convolution was applied to the SAMPLED rows (conv(interp(P)) =
+    interp(conv(P)), include/pn2_hip.h "first convolution HOISTED"), interpolated and given their train-mode BatchNorm
+    statistics by one launch.  The pair is a LazyRows: the next chain links to it; what comes back is the gradient with
+    respect to relu(bn(y)), and the backward scatters dZ(dout, y) to dq without storing it.  meta["rc"]: the dense side is
+    ragged clouds (ops.RaggedClouds), otherwise B clouds of rows / B points."""
 
     @staticmethod
     def forward(ctx, q, idx32, w, gamma, beta, bias, meta):
@@ -400,8 +401,10 @@ class _InterpBNFn(torch.autograd.Function):
         lib = _hip.lib()
         from . import ops
         B, S, C = q.shape
-        N = idx32.shape[1]
-        rows, dev = B * N, q.device
+        rc = meta.get("rc")
+        rows = rc.rows if rc is not None else idx32.numel() // 3
+        N = rc.n_max if rc is not None else rows // B
+        dev = q.device
         q = _hip.f32(q).contiguous()
         seg_ptr, seg_keep = _hip.segments_arg(meta.get("seg_off"))
         nseg = 1 if seg_ptr is None else len(meta["seg_off"]) - 1
@@ -414,12 +417,13 @@ class _InterpBNFn(torch.autograd.Function):
         L.running_mean, L.running_var = _hip.ptr(meta["running_mean"]), _hip.ptr(meta["running_var"])
         L.eps, L.momentum = meta["eps"], meta["momentum"]
         L.y, L.stats = y.data_ptr(), st.data_ptr()
-        ws = torch.empty(lib.pn2_interp_bn_workspace_bytes(B, N, S, C, nseg), dtype=torch.uint8, device=dev)
-        _hip.call("interp_bn_fwd", lib.pn2_interp_bn_fwd_f32, q.data_ptr(), idx32.data_ptr(), w.data_ptr(), B, N, S,
+        ws = torch.empty(lib.pn2_interp_bn_workspace_bytes(B, rows, S, C, nseg), dtype=torch.uint8, device=dev)
+        _hip.call("interp_bn_fwd", lib.pn2_interp_bn_fwd_f32, q.data_ptr(), idx32.data_ptr(), w.data_ptr(),
+                  None if rc is None else rc.coff.data_ptr(), None if rc is None else rc.row_cloud.data_ptr(), B, N, S, rows,
                   ctypes.byref(L), seg_ptr, ops.status_word(dev).data_ptr(), ws.data_ptr(), ws.numel(), _hip.stream_ptr(),
                   nbytes=rows * (36 + 4 * C) + 4 * B * S * C)
         ctx.save_for_backward(idx32, w, y, st, gamma, beta, bias)
-        ctx.meta, ctx.layer, ctx.dims = meta, L, (B, N, S, C, nseg)
+        ctx.meta, ctx.layer, ctx.dims = meta, L, (B, N, S, C, nseg, rows)
         ctx.mark_non_differentiable(st)
         return y, st
 
@@ -427,8 +431,9 @@ class _InterpBNFn(torch.autograd.Function):
     def backward(ctx, dout, _):
         lib = _hip.lib()
         idx32, w, y, st, gamma, beta, bias = ctx.saved_tensors
-        B, N, S, C, nseg = ctx.dims
+        B, N, S, C, nseg, rows = ctx.dims
         meta, L, dev = ctx.meta, ctx.layer, dout.device
+        rc = meta.get("rc")
         dout = _hip.f32(dout).contiguous()
         leaves = meta.get("leaves", (None, None, None))
         tg, dg = _grad_target(leaves[0], gamma, ctx.needs_input_grad[3], dev)
@@ -442,23 +447,107 @@ class _InterpBNFn(torch.autograd.Function):
             L.out_partial = None
         dq = torch.empty(B, S, C, dtype=torch.float32, device=dev)
         seg_ptr, seg_keep = _hip.segments_arg(meta.get("seg_off"))
-        ws = torch.empty(lib.pn2_interp_bn_workspace_bytes(B, N, S, C, nseg), dtype=torch.uint8, device=dev)
-        _hip.call("interp_bn_bwd", lib.pn2_interp_bn_bwd_f32, dout.data_ptr(), idx32.data_ptr(), w.data_ptr(), B, N, S,
-                  ctypes.byref(L), dq.data_ptr(), seg_ptr, ws.data_ptr(), ws.numel(), _hip.stream_ptr(),
-                  nbytes=B * N * (36 + 8 * C) + 4 * B * S * C)
+        ws = torch.empty(lib.pn2_interp_bn_workspace_bytes(B, rows, S, C, nseg), dtype=torch.uint8, device=dev)
+        _hip.call("interp_bn_bwd", lib.pn2_interp_bn_bwd_f32, dout.data_ptr(), idx32.data_ptr(), w.data_ptr(),
+                  None if rc is None else rc.coff.data_ptr(), B, N, S, rows, ctypes.byref(L), dq.data_ptr(), seg_ptr,
+                  ws.data_ptr(), ws.numel(), _hip.stream_ptr(), nbytes=rows * (36 + 8 * C) + 4 * B * S * C)
         return dq, None, None, dg, dbe, dbias, None
 
 
+class _GroupBNFn(torch.autograd.Function):
+    """forward(gf [B,N,C], xyz [B,N,3], new_xyz [B,S,3], idx32 [B,S,K], weight [C, 3+D] view of the level's first conv, gamma,
+    beta, bias, meta) -> (y [B*S*K, C] pre-BatchNorm rows, stats): the grouped rows of a set-abstraction level whose first
+    conv was applied to the SOURCE points (include/pn2_hip.h "Set abstraction with the first convolution HOISTED"):
+    y = gf[idx] + W_x (xyz[idx] - centre), with the layer's train-mode BatchNorm statistics from the same launch.  The pair is
+    a LazyRows for the chain of the remaining layers; the backward scatters dZ(dout, y) to dgf and sums the coordinate
+    weights' gradient.  meta["xcol"]: first coordinate column of the weight (0, or D in the multi-scale channel order)."""
+
+    @staticmethod
+    def forward(ctx, gf, xyz, new_xyz, idx32, weight, gamma, beta, bias, meta):
+        _hip.require_device(gf)
+        lib = _hip.lib()
+        from . import ops
+        B, N, C = gf.shape
+        _, S, K = idx32.shape
+        rows, dev = B * S * K, gf.device
+        gf = _hip.f32(gf).contiguous()
+        xyz, new_xyz = _hip.f32(xyz), _hip.f32(new_xyz).contiguous()
+        weight = weight if weight.stride(1) == 1 else weight.contiguous()
+        seg_ptr, seg_keep = _hip.segments_arg(meta.get("seg_off"))
+        nseg = 1 if seg_ptr is None else len(meta["seg_off"]) - 1
+        y = torch.empty(rows, C, dtype=torch.float32, device=dev)
+        st = torch.empty(8 * nseg, C, dtype=torch.float32, device=dev)
+        L = _hip.MLPLayer()
+        L.cin = L.cout = C
+        L.has_bn, L.relu = 1, int(meta["relu"])
+        L.gamma, L.beta = _hip.ptr(gamma), _hip.ptr(beta)
+        L.running_mean, L.running_var = _hip.ptr(meta["running_mean"]), _hip.ptr(meta["running_var"])
+        L.eps, L.momentum = meta["eps"], meta["momentum"]
+        L.y, L.stats = y.data_ptr(), st.data_ptr()
+        ws = torch.empty(lib.pn2_group_bn_workspace_bytes(B, S, K, C, nseg), dtype=torch.uint8, device=dev)
+        xs = (xyz.stride(0), xyz.stride(1), xyz.stride(2))
+        _hip.call("group_bn_fwd", lib.pn2_group_bn_fwd_f32, gf.data_ptr(), xyz.data_ptr(), *xs, new_xyz.data_ptr(), idx32.data_ptr(),
+                  weight.data_ptr() + 4 * int(meta["xcol"]), weight.stride(0), B, N, S, K, ctypes.byref(L), seg_ptr,
+                  ops.status_word(dev).data_ptr(), ws.data_ptr(), ws.numel(), _hip.stream_ptr(),
+                  nbytes=rows * (8 * C + 20), flops=6 * rows * C)
+        ctx.save_for_backward(xyz, new_xyz, idx32, y, st, gamma, beta, bias)
+        ctx.meta, ctx.layer, ctx.dims, ctx.wshape = meta, L, (B, N, S, K, C, nseg), tuple(weight.shape)
+        ctx.mark_non_differentiable(st)
+        return y, st
+
+    @staticmethod
+    def backward(ctx, dout, _):
+        lib = _hip.lib()
+        xyz, new_xyz, idx32, y, st, gamma, beta, bias = ctx.saved_tensors
+        B, N, S, K, C, nseg = ctx.dims
+        meta, L, dev = ctx.meta, ctx.layer, dout.device
+        rows = B * S * K
+        dout = _hip.f32(dout).contiguous()
+        leaves = meta.get("leaves", (None, None, None))
+        tg, dg = _grad_target(leaves[0], gamma, ctx.needs_input_grad[5], dev)
+        tbe, dbe = _grad_target(leaves[1], beta, ctx.needs_input_grad[6], dev)
+        _, dbias = _grad_target(leaves[2], bias, bias is not None and ctx.needs_input_grad[7], dev)   # zeros
+        L.dgamma, L.dbeta = _hip.ptr(tg), _hip.ptr(tbe)
+        handed = meta["lazy_handle"].pop("partial", None)
+        if handed is not None:
+            L.out_partial, L.out_partial_rows, L.out_partial_cpb = handed[0].data_ptr(), handed[1], handed[2]
+        else:
+            L.out_partial = None
+        dgf = torch.empty(B, N, C, dtype=torch.float32, device=dev)
+        dw = torch.zeros(ctx.wshape, dtype=torch.float32, device=dev)      # only the three coordinate columns are written
+        seg_ptr, seg_keep = _hip.segments_arg(meta.get("seg_off"))
+        ws = torch.empty(lib.pn2_group_bn_workspace_bytes(B, S, K, C, nseg), dtype=torch.uint8, device=dev)
+        xs = (xyz.stride(0), xyz.stride(1), xyz.stride(2))
+        _hip.call("group_bn_bwd", lib.pn2_group_bn_bwd_f32, dout.data_ptr(), xyz.data_ptr(), *xs, new_xyz.data_ptr(), idx32.data_ptr(),
+                  B, N, S, K, ctypes.byref(L), dgf.data_ptr(), dw.data_ptr() + 4 * int(meta["xcol"]), dw.stride(0), seg_ptr,
+                  ws.data_ptr(), ws.numel(), _hip.stream_ptr(), nbytes=rows * (8 * C + 20) + 4 * B * N * C, flops=8 * rows * C)
+        return dgf, None, None, None, dw, dg, dbe, dbias, None
+
+
 HOIST_WIDTHS = (64, 128, 256)
+HOIST_GROUP_WIDTHS = (32, 64, 128, 256)
+# a set-abstraction level is hoisted when it has at least this many grouped rows (smaller levels run as one cooperative
+# launch, which a linked chain cannot) and more grouped rows than source points
+HOIST_GROUP_MIN_ROWS = 32768
 
 
-def interp_bn_rows(q, idx32, w, bn, relu=True, seg_off=None, bias=None):
+def interp_bn_rows(q, idx32, w, bn, relu=True, seg_off=None, bias=None, rc=None):
     """q [B,S,C] = the level's first conv applied to the sampled rows; idx32 / w: three_nn of the dense points ->
     LazyRows of relu(bn(interp(q))) over the B*N dense rows (train-mode `bn`, C in HOIST_WIDTHS); see _InterpBNFn.
-    bias: that conv's bias parameter when q was computed with a DETACHED copy of it (hoisted_conv): it gets a zero gradient."""
+    bias: that conv's bias parameter when q was computed with a DETACHED copy of it (hoisted_conv): it gets a zero gradient.
+    rc: the dense side as ops.RaggedClouds (idx32 / w packed rows) instead of B equal clouds; seg_off: row segments made of
+    whole clouds, as for chain_rows."""
+    meta = _bn_meta(bn, relu, seg_off, (bn.weight, bn.bias, bias))
+    meta["rc"] = rc
+    y, st = _InterpBNFn.apply(q, idx32, w, bn.weight, bn.bias, bias, meta)
+    return LazyRows(y, st, bool(relu), meta.get("seg_off"), meta["lazy_handle"])
+
+
+def _bn_meta(bn, relu, seg_off, leaves):
+    """BatchNorm bookkeeping shared by the hoisted-layer functions -> meta; bumps num_batches_tracked."""
     bump = []
     meta = {"relu": bool(relu), "eps": float(bn.eps), "momentum": _bn_momentum(bn, bump), "running_mean": None,
-            "running_var": None, "leaves": (bn.weight, bn.bias, bias), "lazy_handle": {}}
+            "running_var": None, "leaves": leaves, "lazy_handle": {}}
     if bn.track_running_stats and bn.running_mean is not None:
         meta["running_mean"], meta["running_var"] = bn.running_mean, bn.running_var
     nseg = 1
@@ -472,7 +561,32 @@ def interp_bn_rows(q, idx32, w, bn, relu=True, seg_off=None, bias=None):
             batched_counters.active.pending += [(t, nseg) for t in bump]
         else:
             torch._foreach_add_(bump, nseg)
-    y, st = _InterpBNFn.apply(q, idx32, w, bn.weight, bn.bias, bias, meta)
+    return meta
+
+
+def group_hoist_ok(conv, bn, n_layers, B, N, S, K, D, device):
+    """May a set-abstraction level run the feature share of its first conv on the source points?"""
+    return (D > 0 and n_layers >= 2 and device.type == "cuda" and GEMM_PRECISION == "f32" and bn is not None and bn.training
+            and conv.out_channels in HOIST_GROUP_WIDTHS and K <= 64 and S * K > N and D % 4 == 0
+            and B * S * K >= int(os.environ.get("PN2_HOIST_GROUP_MIN_ROWS", HOIST_GROUP_MIN_ROWS))
+            and not os.environ.get("PN2_NO_HOIST") and not os.environ.get("PN2_NO_HOIST_GROUP")
+            and not os.environ.get("PN2_NO_LAZY_ROWS"))
+
+
+def group_bn_rows(xyz, new_xyz, feats, idx32, conv, bn, xyz_last=False, relu=True, seg_off=None):
+    """The first layer of a set-abstraction level on its grouped rows without forming them: xyz [B,N,3], new_xyz [B,S,3],
+    feats [B,N,D], idx32 [B,S,K] (ball query) -> LazyRows of relu(bn(conv([xyz[idx] - centre, feats[idx]]))) over the B*S*K
+    rows (channel order [feats, xyz - centre] with xyz_last); see _GroupBNFn."""
+    B, N, D = feats.shape
+    W = conv.weight.reshape(conv.out_channels, -1)                      # [C, 3 + D] view of the parameter
+    fcol, xcol = (0, D) if xyz_last else (3, 0)
+    wf = W[:, fcol:fcol + D].contiguous()                               # (autograd sends its gradient back into the slice)
+    bare = _BareConv(conv)
+    bare.weight = wf
+    gf = chain_rows(feats.reshape(B * N, D), [(bare, None, False)])     # [B*N, C], bias included
+    meta = _bn_meta(bn, relu, seg_off, (bn.weight, bn.bias, conv.bias))
+    meta["xcol"] = xcol
+    y, st = _GroupBNFn.apply(gf.view(B, N, -1), xyz, new_xyz, idx32, W, bn.weight, bn.bias, conv.bias, meta)
     return LazyRows(y, st, bool(relu), meta.get("seg_off"), meta["lazy_handle"])
 
 

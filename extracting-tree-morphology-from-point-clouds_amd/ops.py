@@ -362,6 +362,17 @@ class RaggedClouds:
             raise RuntimeError("RaggedClouds: too many points for one pass")
         self.coff_host = off
         self.coff = torch.tensor(off, dtype=torch.int32).to(xyz_cf.device, non_blocking=True)
+        self._row_cloud = None
+
+    @property
+    def row_cloud(self):
+        """int32 [rows]: the cloud of every packed row (built on first use; pn2_interp_bn_fwd_f32 reads it)."""
+        if self._row_cloud is None:
+            dev = self.xyz_cf.device
+            reps = torch.tensor(self.lengths, dtype=torch.int64).to(dev, non_blocking=True)
+            self._row_cloud = torch.repeat_interleave(torch.arange(self.C, dtype=torch.int32, device=dev), reps,
+                                                      output_size=self.rows)
+        return self._row_cloud
 
 
 def fps_ragged(rc, npoint, start):

@@ -36,8 +36,8 @@ import torch
 import torch.nn.functional as F
 
 from . import _hip, ops
-from .mlp import batched_counters, chain_pair_rows, chain_rows
-from .PointNet2.blocks import PointNetSetAbstractionMsg, _group_mlp_max
+from .mlp import batched_counters, chain_pair_rows, chain_rows, group_hoist_ok, hoist_ok, hoisted_conv, interp_bn_rows
+from .PointNet2.blocks import PointNetSetAbstractionMsg, _group_mlp_max, _hoisted_group_mlp_max
 
 MAX_ROWS_PER_PASS = 6_000_000       # level-0 rows (padded points) per pass: ~60 GB of activations at depth 5
 
@@ -121,6 +121,12 @@ def _sa_level(sa, xyz_t, pts_t, start, layout, rc=None):
             grouped = ops.group_ragged(rc, new_xyz, idx, xyz_last=msg)
         else:
             idx = ops.ball_query(radius, K, xyz_t, new_xyz)
+            Cn, Nn = xyz_t.shape[0], xyz_t.shape[1]
+            if pts_t is not None and group_hoist_ok(convs[0], bns[0], len(convs), Cn, Nn, idx.shape[1], idx.shape[2], pts_t.shape[2],
+                                                    xyz_t.device):
+                outs.append(_hoisted_group_mlp_max(xyz_t, new_xyz, pts_t, idx, convs, bns, msg,
+                                                   seg_off=layout.seg_rows(idx.shape[1] * idx.shape[2])))
+                continue
             grouped = ops.GroupPoints.apply(xyz_t, new_xyz, pts_t, idx, msg)
         rows_per_cloud = grouped.shape[1] * grouped.shape[2]
         outs.append(_group_mlp_max(grouped, convs, bns, seg_off=layout.seg_rows(rows_per_cloud),
@@ -137,8 +143,15 @@ def _fp_level(fp, x1, x2, p1, p2, layout, rc=None, lazy=False):
         if S == 1:
             raise RuntimeError("feature propagation from a single sampled point onto ragged clouds is not supported")
         idx, w = ops.three_nn_ragged(rc, x2)
-        feats = ops.ThreeInterpolateRagged.apply(p2, idx, w, rc)
-        return chain_rows(feats, layers, seg_off=layout.rows0.tolist(), lazy_out=lazy)   # lazy: a mlp.LazyRows for the heads
+        seg0 = layout.rows0.tolist()
+        if hoist_ok(fp.mlp_convs[0], fp.mlp_bns[0], len(layers), x2.device):
+            # no skip connection at level 0: the first conv runs on the C * S sampled rows (mlp.interp_bn_rows)
+            q = hoisted_conv(p2.reshape(C * S, -1), fp.mlp_convs[0])
+            feats = interp_bn_rows(q.view(C, S, -1), idx, w, fp.mlp_bns[0], seg_off=seg0, bias=fp.mlp_convs[0].bias, rc=rc)
+            layers = layers[1:]
+        else:
+            feats = ops.ThreeInterpolateRagged.apply(p2, idx, w, rc)
+        return chain_rows(feats, layers, seg_off=seg0, lazy_out=lazy)   # lazy: a mlp.LazyRows for the heads
     N = x1.shape[1]
     if S == 1:
         feats = p2.repeat(1, N, 1)

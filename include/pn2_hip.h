@@ -422,22 +422,51 @@ int pn2_mlp_reduce_wgrad(const pn2_wgrad_task *tasks, int n, void *stream);
  *
  * pn2_interp_bn_fwd_f32   y[r][:] = (q[i0]*w0 + q[i1]*w1) + q[i2]*w2 (the reference's operation order), the per-chunk
  *   (mean, M2) statistics partials from the same registers, then the finalize of the chain kernels: layer->stats gets the
- *   coefficient block(s), the running statistics advance.  q: [B][S][C] rows, idx / w: [B*N][3] (three_nn), layer: cout = C
- *   (64, 128 or 256), has_bn = 1, gamma .. momentum, y [B*N][C], stats [nseg][8][C].  The result is exactly a chain's
+ *   coefficient block(s), the running statistics advance.  q: [B][S][C] rows, idx / w: [rows][3] (three_nn), layer: cout = C
+ *   (64, 128 or 256), has_bn = 1, gamma .. momentum, y [rows][C], stats [nseg][8][C].  The result is exactly a chain's
  *   PN2_CHAIN_LAZY_OUT output: the next chain links to (y, stats) through layers[0].in_stats.
  * pn2_interp_bn_bwd_f32   dout = gradient with respect to relu(bn(y)) (what the linked consumer's dgrad leaves; its
  *   BatchNorm-backward sums through layer->out_partial as between linked chains, NULL: reduced here).  Finalizes dgamma /
  *   dbeta (accumulated) and the backward coefficients, then scatters dZ(dout, y) -- rebuilt while the rows are read, never
  *   stored -- to dq [B][S][C] with the bucketed reduction of pn2_three_interpolate_grad_f32.
- * Rounding: the same products summed in another order (~1e-7 relative); `segments` as for the chains (whole clouds per
- * segment).  workspace: pn2_interp_bn_workspace_bytes() for either direction. */
-size_t pn2_interp_bn_workspace_bytes(int B, int N, int S, int C, int nseg);
-int pn2_interp_bn_fwd_f32(const float *q, const int32_t *idx, const float *w, int B, int N, int S,
-                          const pn2_mlp_layer *layer, const pn2_segments *segments, int32_t *status, void *workspace,
-                          size_t workspace_bytes, void *stream);
-int pn2_interp_bn_bwd_f32(const float *dout, const int32_t *idx, const float *w, int B, int N, int S,
-                          const pn2_mlp_layer *layer, float *dq, const pn2_segments *segments, void *workspace,
-                          size_t workspace_bytes, void *stream);
+ * Dense side: B clouds of N rows (coff = row_cloud = NULL, rows = B*N), or ragged clouds ("Ragged clouds" below: coff
+ * device [B + 1] row offsets, N = the longest cloud, rows = coff[B], row_cloud device [rows] = the cloud of every packed row).
+ * Rounding: the same products summed in another order (~1e-7 relative); `segments` as for the chains, every segment made
+ * of whole clouds.  workspace: pn2_interp_bn_workspace_bytes() for either direction. */
+size_t pn2_interp_bn_workspace_bytes(int B, long long rows, int S, int C, int nseg);
+int pn2_interp_bn_fwd_f32(const float *q, const int32_t *idx, const float *w, const int32_t *coff, const int32_t *row_cloud,
+                          int B, int N, int S, long long rows, const pn2_mlp_layer *layer, const pn2_segments *segments,
+                          int32_t *status, void *workspace, size_t workspace_bytes, void *stream);
+int pn2_interp_bn_bwd_f32(const float *dout, const int32_t *idx, const float *w, const int32_t *coff, int B, int N, int S,
+                          long long rows, const pn2_mlp_layer *layer, float *dq, const pn2_segments *segments,
+                          void *workspace, size_t workspace_bytes, void *stream);
+
+/* Set abstraction with the first convolution HOISTED in front of the grouping   (blocks.py:74-98, pointnet2_utils.py:156-161)
+ *
+ * The first layer of a set-abstraction level is conv([xyz_j - c_s, feats_j]) over the B*S*K grouped rows.  The conv is
+ * linear and a grouped row is a gather, so its feature share is computed ONCE PER SOURCE POINT, gf = W_f feats + bias over
+ * the B*N source rows (a chain call of one bare conv layer) -- N instead of S*K rows per cloud, e.g. 100 instead of 1600 at
+ * the second level of a raster -- and the grouped rows of the layer are gf[idx] + W_x (xyz[idx] - c), the coordinate share
+ * being three multiply-adds per channel on the same centred differences the reference forms.  The [rows][3 + D] grouped
+ * tensor and its odd-width contraction (67 / 131 / 259 input channels) no longer exist.
+ *
+ * pn2_group_bn_fwd_f32   y[(b,s,k)][:] = gf[b][idx[b][s][k]][:] + W_x (xyz[b][idx] - new_xyz[b][s]), the (mean, M2) statistics
+ *   partials from the same registers, then the chain kernels' finalize: exactly a chain's PN2_CHAIN_LAZY_OUT output, which
+ *   the chain of the remaining layers (with its max over K) links to.  gf [B][N][C]; xyz strided as everywhere; wx = the
+ *   coordinate columns of the layer's weight, element (c, d) at wx[c*ldw + d]; layer: cout = C (32, 64, 128 or 256), has_bn,
+ *   gamma .. momentum, y [B*S*K][C], stats; K <= 64.
+ * pn2_group_bn_bwd_f32   dout = gradient with respect to relu(bn(y)); BatchNorm-backward sums through layer->out_partial or
+ *   reduced here; dgamma / dbeta accumulated; dZ(dout, y) is rebuilt row by row and scattered to dgf [B][N][C] (overwritten),
+ *   the coordinate weights' gradient sum dZ (x) (xyz - c) is written to dwx[c*lddw + d].  No gradient for the coordinates.
+ * `segments`: whole clouds per segment.  workspace: pn2_group_bn_workspace_bytes() for either direction. */
+size_t pn2_group_bn_workspace_bytes(int B, int S, int K, int C, int nseg);
+int pn2_group_bn_fwd_f32(const float *gf, const float *xyz, int64_t sb, int64_t sn, int64_t sc, const float *new_xyz,
+                         const int32_t *idx, const float *wx, int64_t ldw, int B, int N, int S, int K,
+                         const pn2_mlp_layer *layer, const pn2_segments *segments, int32_t *status, void *workspace,
+                         size_t workspace_bytes, void *stream);
+int pn2_group_bn_bwd_f32(const float *dout, const float *xyz, int64_t sb, int64_t sn, int64_t sc, const float *new_xyz,
+                         const int32_t *idx, int B, int N, int S, int K, const pn2_mlp_layer *layer, float *dgf, float *dwx,
+                         int64_t lddw, const pn2_segments *segments, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * PointTransformerV3 serialized patch attention   replaces Modules/PointTransformerV3/blocks.py:384-437 and :457-488

@@ -156,3 +156,102 @@ def test_hoisted_level_really_runs_and_reduces_its_own_sums():
         if k.startswith("b") and not k.startswith("be"):
             continue
         _close(own[k], linked[k], 1e-5, f"own sums vs linked sums: {k}")
+
+
+def test_hoisted_level_on_ragged_clouds_with_segments():
+    """Whole-tree execution (streaming.run_tree: ragged level-0 clouds, one BatchNorm segment per mini-batch) with fp1's first
+    conv hoisted against the same pass with PN2_NO_HOIST=1: losses, accumulated gradients, BatchNorm buffers."""
+    import numpy as np
+    from test_streaming import _Scaler, _grads_close, _tree_minibatches
+    helpers.load_pkg()
+    from pn2_amd.PointNet2.PointNet2 import PointNet2
+    mbs, labels = _tree_minibatches(30000, seed=5, mbs=8)
+    assert len(mbs) >= 3
+    res = {}
+    for hoist in (False, True):
+        with env(PN2_STREAMING="fused", **({} if hoist else {"PN2_NO_HOIST": 1})):
+            torch.manual_seed(11)
+            model = PointNet2(depth=5).cuda().train()
+            torch.manual_seed(12)
+            loss, ld = model.forward_hierarchical_streaming(dict(labels, mini_batches=iter(mbs)), return_loss=True, scaler=_Scaler())
+            res[hoist] = (float(loss), {n: p.grad.detach().clone() for n, p in model.named_parameters()},
+                          {n: b.detach().clone() for n, b in model.named_buffers()})
+    (l0, g0, b0), (l1, g1, b1) = res[False], res[True]
+    assert abs(l0 - l1) <= 1e-5 * abs(l0)
+    _grads_close(g0, g1)
+    for n in b0:
+        if "num_batches" in n:
+            assert int(b0[n]) == int(b1[n])
+        else:
+            np.testing.assert_allclose(b1[n].cpu().numpy(), b0[n].cpu().numpy(), rtol=1e-4, atol=1e-5)
+
+
+def _sa_run(sa, xyz, pts, hoist):
+    for p in sa.parameters():
+        p.grad = None
+    for m in sa.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.running_mean.zero_()
+            m.running_var.fill_(1.0)
+            m.num_batches_tracked.zero_()
+    pin = pts.clone().requires_grad_(True)
+    kw = {"PN2_HOIST_GROUP_MIN_ROWS": 1} if hoist else {"PN2_NO_HOIST_GROUP": 1}
+    names = []
+    from pn2_amd import _hip
+    orig = _hip.call
+
+    def spy(name, fn, *a, **k):
+        names.append(name)
+        return orig(name, fn, *a, **k)
+
+    _hip.call = spy
+    try:
+        with env(**kw):
+            torch.manual_seed(4)                          # the FPS start draws
+            new_xyz, y = sa(xyz, pin)
+            wgt = torch.cos(torch.arange(y.numel(), device="cuda", dtype=torch.float32) * 0.37).view_as(y)
+            (y * wgt).sum().backward()
+    finally:
+        _hip.call = orig
+    torch.cuda.synchronize()
+    out = {"new_xyz": new_xyz.detach().clone(), "y": y.detach().clone(), "dpts": pin.grad.clone()}
+    for n, p in sa.named_parameters():
+        out["grad:" + n] = p.grad.clone()
+    for n, b in sa.named_buffers():
+        out["buf:" + n] = b.detach().clone().float()
+    return out, names
+
+
+@pytest.mark.parametrize("msg,B,N,S,K,D,widths", [
+    (False, 3, 400, 64, 32, 64, [64, 64, 128]),        # second level of a raster pass
+    (False, 2, 100, 50, 32, 128, [128, 128, 256]),     # more groups than a source point can fill: padded balls
+    (False, 5, 300, 40, 16, 32, [32, 64]),             # C = 32 (512-row blocks), K = 16
+    (True, 2, 500, 48, 32, 64, [64, 128]),             # multi-scale channel order [feats, xyz]
+])
+def test_hoisted_set_abstraction_matches_plain_path(msg, B, N, S, K, D, widths):
+    helpers.load_pkg()
+    from pn2_amd.PointNet2.blocks import PointNetSetAbstraction, PointNetSetAbstractionMsg
+    torch.manual_seed(21)
+    if msg:
+        sa = PointNetSetAbstractionMsg(S, [0.25, 0.4], [K, K], D + 3, [widths, widths]).cuda().train()
+    else:
+        sa = PointNetSetAbstraction(S, 0.3, K, D + 3, widths, False).cuda().train()
+    with torch.no_grad():
+        for m in sa.modules():
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.3, 0.3)
+    g = torch.Generator().manual_seed(8)
+    xyz = (torch.rand(B, 3, N, generator=g) + 3.0).cuda()           # off-centre clouds: the coordinates are centred per group
+    pts = torch.randn(B, D, N, generator=g).cuda()
+    plain, n0 = _sa_run(sa, xyz, pts, hoist=False)
+    hoisted, n1 = _sa_run(sa, xyz, pts, hoist=True)
+    assert "group_bn_fwd" in n1 and "group_bn_bwd" in n1 and "group_points" not in n1
+    assert "group_points" in n0 and "group_bn_fwd" not in n0
+    for k in plain:
+        if k.startswith("grad:") and k.endswith("0.bias") and "convs" in k:
+            continue                                                  # (zero gradient: rounding noise on the plain path)
+        if "num_batches" in k or k == "new_xyz":
+            assert torch.equal(hoisted[k], plain[k]), k
+        else:
+            _close(hoisted[k], plain[k], 3e-5, f"hoisted vs plain: {k}")
