@@ -565,9 +565,10 @@ def _bn_meta(bn, relu, seg_off, leaves):
 
 
 def group_hoist_ok(conv, bn, n_layers, B, N, S, K, D, device):
-    """May a set-abstraction level run the feature share of its first conv on the source points?"""
+    """May a set-abstraction level run the feature share of its first conv on the source points?  (Not the first level: its few
+    input features are no contraction worth moving, and in whole-tree execution its clouds are ragged.)"""
     return (D > 0 and n_layers >= 2 and device.type == "cuda" and GEMM_PRECISION == "f32" and bn is not None and bn.training
-            and conv.out_channels in HOIST_GROUP_WIDTHS and K <= 64 and S * K > N and D % 4 == 0
+            and conv.out_channels in HOIST_GROUP_WIDTHS and K <= 64 and S * K > N and D % 4 == 0 and D >= 32
             and B * S * K >= int(os.environ.get("PN2_HOIST_GROUP_MIN_ROWS", HOIST_GROUP_MIN_ROWS))
             and not os.environ.get("PN2_NO_HOIST") and not os.environ.get("PN2_NO_HOIST_GROUP")
             and not os.environ.get("PN2_NO_LAZY_ROWS"))

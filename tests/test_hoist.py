@@ -225,7 +225,7 @@ def _sa_run(sa, xyz, pts, hoist):
 @pytest.mark.parametrize("msg,B,N,S,K,D,widths", [
     (False, 3, 400, 64, 32, 64, [64, 64, 128]),        # second level of a raster pass
     (False, 2, 100, 50, 32, 128, [128, 128, 256]),     # more groups than a source point can fill: padded balls
-    (False, 5, 300, 40, 16, 32, [32, 64]),             # C = 32 (512-row blocks), K = 16
+    (False, 5, 300, 40, 16, 32, [32, 64]),             # C = 32 (512-row blocks, half a wavefront of channels), K = 16
     (True, 2, 500, 48, 32, 64, [64, 128]),             # multi-scale channel order [feats, xyz]
 ])
 def test_hoisted_set_abstraction_matches_plain_path(msg, B, N, S, K, D, widths):
@@ -255,3 +255,48 @@ def test_hoisted_set_abstraction_matches_plain_path(msg, B, N, S, K, D, widths):
             assert torch.equal(hoisted[k], plain[k]), k
         else:
             _close(hoisted[k], plain[k], 3e-5, f"hoisted vs plain: {k}")
+
+
+def test_hoisted_set_abstraction_with_row_segments():
+    """Whole-tree execution hands a level the clouds of ALL mini-batches with one BatchNorm segment per mini-batch: the hoisted
+    level against the grouped-tensor path on the same segments (per-segment statistics, coefficient blocks, running buffers)."""
+    helpers.load_pkg()
+    from pn2_amd import ops
+    from pn2_amd.PointNet2.blocks import PointNetSetAbstraction, _group_mlp_max, _hoisted_group_mlp_max
+    B, N, S, K, D = 7, 300, 40, 32, 64
+    torch.manual_seed(31)
+    sa = PointNetSetAbstraction(S, 0.3, K, D + 3, [64, 64, 128], False).cuda().train()
+    g = torch.Generator().manual_seed(9)
+    xyz = (torch.rand(B, N, 3, generator=g) - 2.0).cuda()
+    pts = torch.randn(B, N, D, generator=g).cuda()
+    start = torch.zeros(B, dtype=torch.int64, device="cuda")
+    _, new_xyz = ops.furthest_point_sample(xyz, S, start)
+    idx = ops.ball_query(0.3, K, xyz, new_xyz)
+    seg = [0, 2 * S * K, 3 * S * K, 7 * S * K]
+    res = {}
+    for hoist in (False, True):
+        for p in sa.parameters():
+            p.grad = None
+        for m in sa.mlp_bns:
+            m.running_mean.zero_()
+            m.running_var.fill_(1.0)
+            m.num_batches_tracked.zero_()
+        pin = pts.clone().requires_grad_(True)
+        if hoist:
+            y = _hoisted_group_mlp_max(xyz, new_xyz, pin, idx, sa.mlp_convs, sa.mlp_bns, False, seg_off=seg)
+        else:
+            grouped = ops.GroupPoints.apply(xyz, new_xyz, pin, idx, False)
+            y = _group_mlp_max(grouped, sa.mlp_convs, sa.mlp_bns, seg_off=seg, coords_first=3)
+        wgt = torch.cos(torch.arange(y.numel(), device="cuda", dtype=torch.float32) * 0.37).view_as(y)
+        (y * wgt).sum().backward()
+        torch.cuda.synchronize()
+        out = {"y": y.detach().clone(), "dpts": pin.grad.clone()}
+        for n, p in sa.named_parameters():
+            out["grad:" + n] = p.grad.clone()
+        for n, b in sa.named_buffers():
+            out["buf:" + n] = b.detach().clone().float()
+        res[hoist] = out
+    for k in res[False]:
+        if k == "grad:mlp_convs.0.bias":
+            continue
+        _close(res[True][k], res[False][k], 3e-5, f"hoisted vs plain with segments: {k}")

@@ -232,6 +232,9 @@ def test_fused_streaming_equals_sequential_loop(pn2, depth, host_inputs):
     res = {}
     for mode in ("sequential", "fused"):
         os.environ["PN2_STREAMING"] = mode
+        # the same arithmetic in both modes: the fused pass hoists the first conv of its (large) set-abstraction levels onto the
+        # source points (mlp.group_bn_rows); the per-mini-batch levels are below that switch's row limit unless told otherwise
+        os.environ["PN2_HOIST_GROUP_MIN_ROWS"] = "1"
         try:
             torch.manual_seed(11)
             model = PointNet2(depth=depth).cuda().train()
@@ -245,6 +248,7 @@ def test_fused_streaming_equals_sequential_loop(pn2, depth, host_inputs):
             res[mode] = (loss, {k: float(v) for k, v in ld.items()}, grads, bufs, pred)
         finally:
             os.environ.pop("PN2_STREAMING", None)
+            os.environ.pop("PN2_HOIST_GROUP_MIN_ROWS", None)
     (l0, d0, g0, b0, p0), (l1, d1, g1, b1, p1) = res["sequential"], res["fused"]
     assert abs(l0 - l1) <= 1e-5 * abs(l0)
     for k in d0:
