@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpn2hip.so")
+LIB_PATH = os.environ.get("PN2_LIB") or os.path.join(_HERE, "libpn2hip.so")   # (PN2_LIB: a diagnostic build, tools/diag_*.py)
 
 _vp = ctypes.c_void_p
 _i64 = ctypes.c_int64

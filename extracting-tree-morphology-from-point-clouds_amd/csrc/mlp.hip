@@ -2228,3 +2228,16 @@ extern "C" int pn2_group_bn_bwd_f32(const float* dout, const float* xyz, int64_t
     PN2_LAUNCH_CHECK();
     return 0;
 }
+
+#ifdef PN2_GEMM_DIAG
+// diagnostic build only: copy the stamp table to the host (synchronises the device)
+extern "C" int pn2_gemm_diag_read(unsigned long long* host, int clear) {
+    PN2_HIP_CHECK(hipDeviceSynchronize());
+    PN2_HIP_CHECK(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gemm_diag), sizeof(unsigned long long) * 16384 * 8));
+    if (clear) {
+        static unsigned long long zeros[16384 * 8];
+        PN2_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_diag), zeros, sizeof(zeros)));
+    }
+    return 0;
+}
+#endif

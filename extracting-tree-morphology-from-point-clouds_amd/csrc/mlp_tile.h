@@ -15,10 +15,36 @@ constexpr int BK = 16, NT = 256;
 #ifndef PN2_DGRAD_OCC
 #define PN2_DGRAD_OCC 2
 #endif
+
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
 enum { TR_PLAIN = 0, TR_BNRELU = 1, TR_DY = 2 };
+
+// Diagnostic build (tools/build_diag.sh, -DPN2_GEMM_DIAG): wave 0 of every workgroup of the one-tile-per-workgroup kernels
+// stamps the shader clock at its phases into g_gemm_diag[linear workgroup][slot] (slot 0: 100 MHz wall clock at entry, 1..4:
+// cycle counter after prepare / after the first tile is staged / after the K loop / after the epilogue, 5: wall clock at the
+// end, 6: hardware id); tools/diag_gemm.py reads them back through pn2_gemm_diag_read().
+#ifdef PN2_GEMM_DIAG
+__device__ unsigned long long g_gemm_diag[16384][8];
+#define PN2_GEMM_STAMP(SLOT)                                                                                           \
+    do {                                                                                                               \
+        if (threadIdx.x == 0) {                                                                                        \
+            const unsigned wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                        \
+            if (wg < 16384) {                                                                                          \
+                if ((SLOT) == 1) {                                                                                     \
+                    g_gemm_diag[wg][0] = wall_clock64();                                                               \
+                    g_gemm_diag[wg][6] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |                 \
+                                         ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32); \
+                }                                                                                                      \
+                g_gemm_diag[wg][SLOT] = clock64();                                                                     \
+                if ((SLOT) == 4) g_gemm_diag[wg][5] = wall_clock64();                                                  \
+            }                                                                                                          \
+        }                                                                                                              \
+    } while (0)
+#else
+#define PN2_GEMM_STAMP(SLOT) do { } while (0)
+#endif
 enum { EPI_FWD = 0, EPI_STORE = 1, EPI_SLAB = 2 };
 // the one-segment table of the cooperative kernels: nothing to search, nothing indexed dynamically
 struct OneSeg {
@@ -532,6 +558,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g0, const TAB& st, con
     sb.tid = tid;
     sa.prepare(g.A, m0);
     sb.prepare(g.B, n0);
+    PN2_GEMM_STAMP(1);
     if (nk > 0) {
         sa.fetch(g.A, m0, k_begin);
         sb.fetch(g.B, n0, k_begin);
@@ -539,6 +566,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g0, const TAB& st, con
         sb.commit(g.B, Bs[0], n0, k_begin);
     }
     __syncthreads();
+    PN2_GEMM_STAMP(2);
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         const int knext = k_begin + (kt + 1) * BK;
@@ -600,6 +628,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g0, const TAB& st, con
         }
         __syncthreads();
     }
+    PN2_GEMM_STAMP(3);
 
     if (TEAMS > 1) {
         // sum the teams' partial tiles through LDS (the staging buffers are free now); team 0 runs the epilogue
@@ -620,6 +649,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g0, const TAB& st, con
     if (TEAMS == 1 || team == 0)
         gemm_epilogue<EPI, NI, COH, (ST & 4) != 0, (ST & 8) != 0>(g, acc, m0 + wm * WT, n0 + wn * WT, WT, lane, BZ,
                                                                   (long long)BX * (TILE / WT) + wm);
+    PN2_GEMM_STAMP(4);
 }
 
 // One tile per workgroup: the launch grid is the tile grid.
