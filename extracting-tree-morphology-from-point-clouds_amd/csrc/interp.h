@@ -13,6 +13,7 @@ struct DySource {
     int relu;
     int nseg;                  // row segments of the packed rows (1: one block serves every row)
     const int32_t* row_off;    // host, nseg + 1 ascending offsets (ignored for nseg <= 1)
+    int rows_bf16;             // dout and y are __bf16 rows (bf16 mode with bfloat16 storage)
 };
 
 size_t grad_workspace_bytes(int B, long long rows, int S);

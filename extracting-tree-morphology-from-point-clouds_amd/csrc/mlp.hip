@@ -1871,7 +1871,9 @@ struct GroupSrc {
     }
 };
 
-template <class SRC>
+// Y16: the rows are stored as bfloat16 (bf16 mode with bfloat16 storage; the statistics come from the fp32 registers, as in
+// the GEMM epilogue)
+template <class SRC, bool Y16 = false>
 __global__ __launch_bounds__(256) void rows_stats_kernel(SRC src, int C, float* __restrict__ y, float* __restrict__ partial,
                                                          long long pchunk, long long pcol, long long pwhich, const SegTable st,
                                                          int32_t* status) {
@@ -1892,7 +1894,12 @@ __global__ __launch_bounds__(256) void rows_stats_kernel(SRC src, int C, float* 
             v[p] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (row < rb.row_end) {
                 v[p] = src.row(row, c, C, status);
-                *(float4*)(y + (long long)row * C + c) = v[p];
+                if (Y16) {
+                    using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+                    *(bf16x4*)((__bf16*)y + (long long)row * C + c) = bf16x4{(__bf16)v[p].x, (__bf16)v[p].y, (__bf16)v[p].z, (__bf16)v[p].w};
+                } else {
+                    *(float4*)(y + (long long)row * C + c) = v[p];
+                }
             }
         }
         float4 s = v[0];
@@ -1960,8 +1967,8 @@ extern "C" size_t pn2_interp_bn_workspace_bytes(int B, long long rows, int S, in
 
 extern "C" int pn2_interp_bn_fwd_f32(const float* q, const int32_t* idx, const float* w, const int32_t* coff,
                                      const int32_t* row_cloud, int B, int N, int S, long long nrows, const pn2_mlp_layer* layer,
-                                     const pn2_segments* segments, int32_t* status, void* workspace, size_t workspace_bytes,
-                                     void* stream) {
+                                     const pn2_segments* segments, int rows_bf16, int32_t* status, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
     if (!q || !aligned16(q) || (coff == nullptr) != (row_cloud == nullptr) ||
         !interp_bn_args_ok(idx, w, coff, B, N, S, nrows, layer, segments))
         return PN2_E_BADARG;
@@ -1977,15 +1984,19 @@ extern "C" int pn2_interp_bn_fwd_f32(const float* q, const int32_t* idx, const f
     const SegTable st = make_table(Sg, R, &nblk);
     const long long cm = cm_stride(rows, R, Sg.nseg);
     const InterpSrc src{q, idx, w, row_cloud, N, S};
-    PN2_LAUNCH("interp_bn_fwd", (double)rows * (36.0 + 4.0 * C) + 4.0 * B * S * C, 0, (rows_stats_kernel<InterpSrc>), dim3(nblk),
-               dim3(256), s, src, C, L.y, part, cm ? 2ll : 2ll * C, cm ? cm : 1ll, cm ? 1ll : (long long)C, st, status);
+    if (rows_bf16)
+        PN2_LAUNCH("interp_bn_fwd", (double)rows * (36.0 + 2.0 * C) + 4.0 * B * S * C, 0, (rows_stats_kernel<InterpSrc, true>), dim3(nblk),
+                   dim3(256), s, src, C, L.y, part, cm ? 2ll : 2ll * C, cm ? cm : 1ll, cm ? 1ll : (long long)C, st, status);
+    else
+        PN2_LAUNCH("interp_bn_fwd", (double)rows * (36.0 + 4.0 * C) + 4.0 * B * S * C, 0, (rows_stats_kernel<InterpSrc>), dim3(nblk),
+                   dim3(256), s, src, C, L.y, part, cm ? 2ll : 2ll * C, cm ? cm : 1ll, cm ? 1ll : (long long)C, st, status);
     PN2_LAUNCH_CHECK();
     return launch_bn_finalize(part, fs, Sg, R, rows, L, s, cm);
 }
 
 extern "C" int pn2_interp_bn_bwd_f32(const float* dout, const int32_t* idx, const float* w, const int32_t* coff, int B, int N,
                                      int S, long long nrows, const pn2_mlp_layer* layer, float* dq, const pn2_segments* segments,
-                                     void* workspace, size_t workspace_bytes, void* stream) {
+                                     int rows_bf16, void* workspace, size_t workspace_bytes, void* stream) {
     // (the scatter finds a row's cloud through its destination: no row -> cloud table on this side)
     if (!dout || !dq || !aligned16(dout) || !interp_bn_args_ok(idx, w, coff, B, N, S, nrows, layer, segments)) return PN2_E_BADARG;
     const pn2_mlp_layer& L = *layer;
@@ -2011,12 +2022,13 @@ extern "C" int pn2_interp_bn_bwd_f32(const float* dout, const int32_t* idx, cons
         int nblk = 0;
         const SegTable tb = make_table(Sg, RB, &nblk);
         PN2_LAUNCH("bn_bwd_reduce", 8.0 * rows * C, 0, (bn_bwd_reduce_kernel<true>), dim3(nblk), dim3(256), s, dout, (long long)C,
-                   (const float*)L.y, (long long)C, rows, C, (const float*)L.stats, L.relu, part, tb, 0, 0);
+                   (const float*)L.y, (long long)C, rows, C, (const float*)L.stats, L.relu, part, tb, rows_bf16 ? 1 : 0,
+                   rows_bf16 ? 1 : 0);
         PN2_LAUNCH_CHECK();
     }
     if ((st_ = launch_bn_bwd_finalize(partial, fs, Sg, R, cpb, rows, L, s, cm))) return st_;
     int32_t one[2] = {0, rows};
-    const pn2::interp::DySource dy{L.y, L.stats, L.relu, Sg.nseg, Sg.nseg > 1 ? Sg.row_off : one};
+    const pn2::interp::DySource dy{L.y, L.stats, L.relu, Sg.nseg, Sg.nseg > 1 ? Sg.row_off : one, rows_bf16 ? 1 : 0};
     char* tws = base + part_bytes;
     return pn2::interp::grad(dout, C, 0, idx, w, B, N, S, C, dq, tws, workspace_bytes - (size_t)(tws - (char*)workspace), s,
                              (const int*)coff, rows, &dy);

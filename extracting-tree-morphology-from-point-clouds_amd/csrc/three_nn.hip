@@ -416,7 +416,7 @@ struct TigDy {
     const float* coef;
     int relu;
 };
-template <bool DY>
+template <bool DY, bool H16 = false>   // H16 (with DY): dout and y are __bf16 rows
 __global__ __launch_bounds__(kBlock) void tig_reduce_kernel(const float* __restrict__ dout, int64_t out_stride, int64_t out_offset,
                                                             const int32_t* __restrict__ idx, const float* __restrict__ w,
                                                             const int* __restrict__ offs, const int* __restrict__ coffs,
@@ -438,7 +438,9 @@ __global__ __launch_bounds__(kBlock) void tig_reduce_kernel(const float* __restr
     if (DY && st.nseg > 1 && lo < hi) coef += (long long)seg_of_row(st, __builtin_amdgcn_readfirstlane(list[lo])) * ST_ROWS * D;
     for (int c0 = 0; c0 < D; c0 += 128) {
         float a0 = 0.0f, a1 = 0.0f;
-        const int ca = c0 + lane, cb = c0 + 64 + lane;
+        // the lane's two channels of the 128-channel block: l and l + 64, or -- bfloat16 rows -- the adjacent pair 2l, 2l + 1
+        // (one 4-byte load per row instead of two 2-byte ones)
+        const int ca = H16 ? c0 + 2 * lane : c0 + lane, cb = H16 ? c0 + 2 * lane + 1 : c0 + 64 + lane;
         float km[2], ks[2], kb[2], ka[2], kq[2];    // DY: the coefficients of channels ca, cb
         if (DY) {
 #pragma unroll
@@ -458,11 +460,21 @@ __global__ __launch_bounds__(kBlock) void tig_reduce_kernel(const float* __restr
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const float* src = dout + (long long)row[u] * out_stride + out_offset;
-                v0[u] = ca < D ? src[ca] : 0.0f;
-                v1[u] = cb < D ? src[cb] : 0.0f;
+                if (H16) {   // (D and the row strides are even, ca is even: 4-byte aligned pairs)
+                    const unsigned short* s16 = (const unsigned short*)dout + (long long)row[u] * out_stride + out_offset;
+                    const unsigned pr = cb < D ? *(const unsigned*)(s16 + ca) : 0u;
+                    v0[u] = __uint_as_float(pr << 16);
+                    v1[u] = __uint_as_float(pr & 0xFFFF0000u);
+                } else {
+                    v0[u] = ca < D ? src[ca] : 0.0f;
+                    v1[u] = cb < D ? src[cb] : 0.0f;
+                }
                 if (DY) {
                     const float* yr = dy.y + (long long)row[u] * D;
-                    const float y0 = ca < D ? yr[ca] : 0.0f, y1 = cb < D ? yr[cb] : 0.0f;
+                    const unsigned short* yh = (const unsigned short*)dy.y + (long long)row[u] * D;
+                    const unsigned ypr = (H16 && cb < D) ? *(const unsigned*)(yh + ca) : 0u;
+                    const float y0 = H16 ? __uint_as_float(ypr << 16) : (ca < D ? yr[ca] : 0.0f);
+                    const float y1 = H16 ? __uint_as_float(ypr & 0xFFFF0000u) : (cb < D ? yr[cb] : 0.0f);
                     const float t0 = __builtin_fmaf(y0 - km[0], ks[0], kb[0]), t1 = __builtin_fmaf(y1 - km[1], ks[1], kb[1]);
                     const float g0 = (!dy.relu || t0 > 0.0f) ? v0[u] : 0.0f, g1 = (!dy.relu || t1 > 0.0f) ? v1[u] : 0.0f;
                     v0[u] = ca < D ? ks[0] * (g0 - ka[0] - (y0 - km[0]) * kq[0]) : 0.0f;
@@ -663,10 +675,10 @@ static int tig_run(const float* dout, int64_t out_stride, int64_t out_offset, co
                    long long rows, const pn2::interp::DySource* dy = nullptr) {
     hipStream_t s = (hipStream_t)stream;
     if (dy && (!dy->y || !dy->coef || out_stride != D || out_offset != 0 || S > 8192 || B > 65535 || dy->nseg > kMaxSegs ||
-               (dy->nseg > 1 && !dy->row_off)))
+               (dy->nseg > 1 && !dy->row_off) || (dy->rows_bf16 && D % 2)))
         return PN2_E_BADARG;
     PN2_HIP_CHECK(hipMemsetAsync(dpoints2, 0, (size_t)B * S * D * sizeof(float), s));
-    const double bytes = (double)rows * (36.0 + (dy ? 8.0 : 4.0) * D) + 4.0 * B * S * D;
+    const double bytes = (double)rows * (36.0 + (dy ? (dy->rows_bf16 ? 4.0 : 8.0) : 4.0) * D) + 4.0 * B * S * D;
     if (!dy && !coff && !tig_sorted(B, N, S, D)) {
         const long long total = (long long)B * N * D;
         PN2_LAUNCH("three_interpolate_grad", bytes, 0, three_interpolate_grad_global_kernel, dim3(grid_for(total)), dim3(kBlock), s,
@@ -706,6 +718,11 @@ static int tig_run(const float* dout, int64_t out_stride, int64_t out_offset, co
         st.nseg = dy->nseg > 1 ? dy->nseg : 1;
         for (int i = 0; i <= st.nseg && dy->nseg > 1; ++i) st.row_off[i] = dy->row_off[i];
         const TigDy td{dy->y, dy->coef, dy->relu};
+        if (dy->rows_bf16)
+            PN2_LAUNCH("three_interpolate_grad", bytes, 0, (tig_reduce_kernel<true, true>), dim3((unsigned)pn2::ceil_div(waves, kBlock / 64)),
+                       dim3(kBlock), s, dout, out_stride, out_offset, idx, w, (const int*)offs, (const int*)coffs, (const int*)list,
+                       BS, S, D, dpoints2, td, st);
+        else
         PN2_LAUNCH("three_interpolate_grad", bytes, 0, (tig_reduce_kernel<true>), dim3((unsigned)pn2::ceil_div(waves, kBlock / 64)),
                    dim3(kBlock), s, dout, out_stride, out_offset, idx, w, (const int*)offs, (const int*)coffs, (const int*)list, BS,
                    S, D, dpoints2, td, st);

@@ -408,7 +408,8 @@ class _InterpBNFn(torch.autograd.Function):
         q = _hip.f32(q).contiguous()
         seg_ptr, seg_keep = _hip.segments_arg(meta.get("seg_off"))
         nseg = 1 if seg_ptr is None else len(meta["seg_off"]) - 1
-        y = torch.empty(rows, C, dtype=torch.float32, device=dev)
+        y16 = bool(meta.get("rows_bf16"))              # bf16 mode with bfloat16 storage: the linked chain keeps bfloat16 rows
+        y = torch.empty(rows, C, dtype=torch.bfloat16 if y16 else torch.float32, device=dev)
         st = torch.empty(8 * nseg, C, dtype=torch.float32, device=dev)
         L = _hip.MLPLayer()
         L.cin = L.cout = C
@@ -420,8 +421,8 @@ class _InterpBNFn(torch.autograd.Function):
         ws = torch.empty(lib.pn2_interp_bn_workspace_bytes(B, rows, S, C, nseg), dtype=torch.uint8, device=dev)
         _hip.call("interp_bn_fwd", lib.pn2_interp_bn_fwd_f32, q.data_ptr(), idx32.data_ptr(), w.data_ptr(),
                   None if rc is None else rc.coff.data_ptr(), None if rc is None else rc.row_cloud.data_ptr(), B, N, S, rows,
-                  ctypes.byref(L), seg_ptr, ops.status_word(dev).data_ptr(), ws.data_ptr(), ws.numel(), _hip.stream_ptr(),
-                  nbytes=rows * (36 + 4 * C) + 4 * B * S * C)
+                  ctypes.byref(L), seg_ptr, int(y16), ops.status_word(dev).data_ptr(), ws.data_ptr(), ws.numel(), _hip.stream_ptr(),
+                  nbytes=rows * (36 + (2 if y16 else 4) * C) + 4 * B * S * C)
         ctx.save_for_backward(idx32, w, y, st, gamma, beta, bias)
         ctx.meta, ctx.layer, ctx.dims = meta, L, (B, N, S, C, nseg, rows)
         ctx.mark_non_differentiable(st)
@@ -434,7 +435,9 @@ class _InterpBNFn(torch.autograd.Function):
         B, N, S, C, nseg, rows = ctx.dims
         meta, L, dev = ctx.meta, ctx.layer, dout.device
         rc = meta.get("rc")
-        dout = _hip.f32(dout).contiguous()
+        y16 = y.dtype == torch.bfloat16
+        dout = (dout if dout.dtype == torch.bfloat16 else dout.to(torch.bfloat16)) if y16 else _hip.f32(dout)
+        dout = dout.contiguous()
         leaves = meta.get("leaves", (None, None, None))
         tg, dg = _grad_target(leaves[0], gamma, ctx.needs_input_grad[3], dev)
         tbe, dbe = _grad_target(leaves[1], beta, ctx.needs_input_grad[4], dev)
@@ -449,8 +452,8 @@ class _InterpBNFn(torch.autograd.Function):
         seg_ptr, seg_keep = _hip.segments_arg(meta.get("seg_off"))
         ws = torch.empty(lib.pn2_interp_bn_workspace_bytes(B, rows, S, C, nseg), dtype=torch.uint8, device=dev)
         _hip.call("interp_bn_bwd", lib.pn2_interp_bn_bwd_f32, dout.data_ptr(), idx32.data_ptr(), w.data_ptr(),
-                  None if rc is None else rc.coff.data_ptr(), B, N, S, rows, ctypes.byref(L), dq.data_ptr(), seg_ptr,
-                  ws.data_ptr(), ws.numel(), _hip.stream_ptr(), nbytes=rows * (36 + 8 * C) + 4 * B * S * C)
+                  None if rc is None else rc.coff.data_ptr(), B, N, S, rows, ctypes.byref(L), dq.data_ptr(), seg_ptr, int(y16),
+                  ws.data_ptr(), ws.numel(), _hip.stream_ptr(), nbytes=rows * (36 + (4 if y16 else 8) * C) + 4 * B * S * C)
         return dq, None, None, dg, dbe, dbias, None
 
 
@@ -539,6 +542,10 @@ def interp_bn_rows(q, idx32, w, bn, relu=True, seg_off=None, bias=None, rc=None)
     whole clouds, as for chain_rows."""
     meta = _bn_meta(bn, relu, seg_off, (bn.weight, bn.bias, bias))
     meta["rc"] = rc
+    # bf16 mode: bfloat16 rows where the chains keep theirs (the full-resolution 128-wide chains, include/pn2_hip.h
+    # PN2_CHAIN_STORE_BF16) -- the linked consumer then runs on bfloat16 rows end to end
+    meta["rows_bf16"] = (GEMM_PRECISION == "bf16" and os.environ.get("PN2_BF16_STORAGE", "1") != "0" and q.shape[2] == 128
+                         and idx32.numel() // 3 >= 32768)
     y, st = _InterpBNFn.apply(q, idx32, w, bn.weight, bn.bias, bias, meta)
     return LazyRows(y, st, bool(relu), meta.get("seg_off"), meta["lazy_handle"])
 
@@ -606,7 +613,7 @@ def hoisted_conv(rows, conv):
 
 def hoist_ok(conv, bn, n_layers, device):
     """May a feature-propagation level without a skip connection run its first conv in front of the interpolation?"""
-    return (n_layers >= 2 and device.type == "cuda" and GEMM_PRECISION == "f32" and bn is not None and bn.training
+    return (n_layers >= 2 and device.type == "cuda" and bn is not None and bn.training
             and conv.out_channels in HOIST_WIDTHS and not os.environ.get("PN2_NO_HOIST")
             and not os.environ.get("PN2_NO_LAZY_ROWS"))
 

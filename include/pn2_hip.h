@@ -432,14 +432,16 @@ int pn2_mlp_reduce_wgrad(const pn2_wgrad_task *tasks, int n, void *stream);
  * Dense side: B clouds of N rows (coff = row_cloud = NULL, rows = B*N), or ragged clouds ("Ragged clouds" below: coff
  * device [B + 1] row offsets, N = the longest cloud, rows = coff[B], row_cloud device [rows] = the cloud of every packed row).
  * Rounding: the same products summed in another order (~1e-7 relative); `segments` as for the chains, every segment made
- * of whole clouds.  workspace: pn2_interp_bn_workspace_bytes() for either direction. */
+ * of whole clouds.  rows_bf16 (bf16 mode with bfloat16 storage, PN2_CHAIN_STORE_BF16): y is written -- and y and dout are
+ * read -- as __bf16 rows, so that the linked chain keeps its bfloat16 rows; q, dq, statistics and sums stay fp32.
+ * workspace: pn2_interp_bn_workspace_bytes() for either direction. */
 size_t pn2_interp_bn_workspace_bytes(int B, long long rows, int S, int C, int nseg);
 int pn2_interp_bn_fwd_f32(const float *q, const int32_t *idx, const float *w, const int32_t *coff, const int32_t *row_cloud,
                           int B, int N, int S, long long rows, const pn2_mlp_layer *layer, const pn2_segments *segments,
-                          int32_t *status, void *workspace, size_t workspace_bytes, void *stream);
+                          int rows_bf16, int32_t *status, void *workspace, size_t workspace_bytes, void *stream);
 int pn2_interp_bn_bwd_f32(const float *dout, const int32_t *idx, const float *w, const int32_t *coff, int B, int N, int S,
                           long long rows, const pn2_mlp_layer *layer, float *dq, const pn2_segments *segments,
-                          void *workspace, size_t workspace_bytes, void *stream);
+                          int rows_bf16, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Set abstraction with the first convolution HOISTED in front of the grouping   (blocks.py:74-98, pointnet2_utils.py:156-161)
  *
