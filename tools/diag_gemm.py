@@ -46,6 +46,10 @@ def report(name, t):
             by.setdefault(k, []).append(i)
         print("   compute units used by the first 768 workgroups:", len(by), " e.g.", list(by.items())[:6])
     print(f"{name}: {len(t)} workgroups, span {span_us:.1f} us, shader clock ~{mhz:.0f} MHz, alive at mid-launch {alive}")
+    lives = np.sort(wall)
+    occ = wall.sum() / (span_us * 256.0)
+    print(f"   life 10/50/90/100 %: {lives[len(lives) // 10]:.1f}/{lives[len(lives) // 2]:.1f}/{lives[9 * len(lives) // 10]:.1f}/{lives[-1]:.1f} us;"
+          f" time-averaged workgroups per compute unit {occ:.2f}")
     print(f"   per workgroup (cycles, median): prologue {med(t[:, 2] - t[:, 1]):.0f} | K loop {med(t[:, 3] - t[:, 2]):.0f} | "
           f"epilogue {med(t[:, 4] - t[:, 3]):.0f} | life {med(cyc):.0f} = {med(wall):.1f} us;  last start at +{starts[-1]:.1f} us, "
           f"10/50/90 % of starts by +{starts[len(starts) // 10]:.1f}/{starts[len(starts) // 2]:.1f}/{starts[9 * len(starts) // 10]:.1f} us")
