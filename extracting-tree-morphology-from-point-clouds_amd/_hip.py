@@ -123,6 +123,7 @@ SIGNATURES = {
     "pn2_mlp_chain_fwd_f32": (_int, [_vp, _i64, _int, _lp, _int, _int, _int, _vp, _vp, _sp, _int, _cp, _vp, _sz, _vp]),
     "pn2_mlp_link_partial_bytes": (_sz, [_int, _int, _int, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "pn2_mlp_reduce_wgrad": (_int, [ctypes.POINTER(WgradTask), _int, _vp]),
+    "pn2_mlp_pair_dgrad_f32": (_int, [_int, _lp, _vp, _lp, _vp, _vp, _i64, _vp, _i64, _sp, _int, _vp]),
     "pn2_group_bn_workspace_bytes": (_sz, [_int, _int, _int, _int, _int]),
     "pn2_group_bn_fwd_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _lp, _sp, _vp, _vp, _sz,
                                     _vp]),

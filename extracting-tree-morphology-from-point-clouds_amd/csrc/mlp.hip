@@ -1042,7 +1042,8 @@ inline int pick_tile(int M, int N, int nsplit) {
 
 // Row-tiled roles (forward, dgrad): grid.x = row tiles of the segments; wgrad: grid.z = reduction ranges of the segments
 // (`g.k_per_split` rows each), grid.x tiles the output rows (= cout).
-template <bool A_T, int A_KIND, bool B_T, int B_KIND, int EPI, int TILE, bool VEC, int TEAMS = 1, bool BF16 = false, int NTT = NT, int ST = 0>
+template <bool A_T, int A_KIND, bool B_T, int B_KIND, int EPI, int TILE, bool VEC, int TEAMS = 1, bool BF16 = false, int NTT = NT, int ST = 0,
+          bool DUAL = false>
 int launch_gemm_tv(GemmArgs& g, const Segs& S, hipStream_t s, int* nblk_out) {
     int nblk = 0;
     const SegTable st = make_table(S, EPI == EPI_SLAB ? g.k_per_split : TILE, &nblk);
@@ -1052,18 +1053,19 @@ int launch_gemm_tv(GemmArgs& g, const Segs& S, hipStream_t s, int* nblk_out) {
     // (the dgrad that closes a pair of linked chains also reads C -- its accumulators start from the sibling's gradient --
     // and the producing layer's rows for its BatchNorm-backward sums: its own group in the profile, with those bytes)
     const bool closing = EPI == EPI_STORE && g.accumulate;
-    const char* name = BF16 ? (EPI == EPI_FWD ? "gemm_fwd_bf16" : EPI == EPI_STORE ? (closing ? "gemm_dgrad_acc_bf16" : "gemm_dgrad_bf16")
+    const char* name = DUAL ? (BF16 ? "gemm_dgrad_pair_bf16" : "gemm_dgrad_pair")
+                       : BF16 ? (EPI == EPI_FWD ? "gemm_fwd_bf16" : EPI == EPI_STORE ? (closing ? "gemm_dgrad_acc_bf16" : "gemm_dgrad_bf16")
                                                                                      : "gemm_wgrad_bf16")
                             : (EPI == EPI_FWD ? "gemm_fwd" : EPI == EPI_STORE ? (closing ? "gemm_dgrad_acc" : "gemm_dgrad") : "gemm_wgrad");
     const double mk = (double)g.M * g.K * (A_KIND == TR_DY ? 2 : 1), kn = (double)g.K * g.N * (B_KIND == TR_DY ? 2 : 1);
     const double extra = (closing ? 1.0 : 0.0) + ((EPI == EPI_STORE && g.partial) ? 1.0 : 0.0);   // C read, ey read
     const double bytes = 4.0 * (mk + kn + (double)g.M * g.N * ((EPI == EPI_SLAB ? nblk : 1) + extra));
-    if (closing)
+    if (closing && !DUAL)
         PN2_LAUNCH(name, bytes, 2.0 * g.M * g.N * g.K,
-                   (gemm_kernel<A_T, A_KIND, B_T, B_KIND, EPI, TILE, VEC, TEAMS, BF16, EPI == EPI_STORE, NTT, ST>), grid, dim3(NTT * TEAMS), s, g,
-                   st);
+                   (gemm_kernel<A_T, A_KIND, B_T, B_KIND, EPI, TILE, VEC, TEAMS, BF16, EPI == EPI_STORE && !DUAL, NTT, ST>), grid,
+                   dim3(NTT * TEAMS), s, g, st);
     else
-        PN2_LAUNCH(name, bytes, 2.0 * g.M * g.N * g.K, (gemm_kernel<A_T, A_KIND, B_T, B_KIND, EPI, TILE, VEC, TEAMS, BF16, false, NTT, ST>),
+        PN2_LAUNCH(name, bytes, 2.0 * g.M * g.N * g.K, (gemm_kernel<A_T, A_KIND, B_T, B_KIND, EPI, TILE, VEC, TEAMS, BF16, false, NTT, ST, DUAL>),
                    grid, dim3(NTT * TEAMS), s, g, st);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
@@ -2253,3 +2255,53 @@ extern "C" int pn2_gemm_diag_read(unsigned long long* host, int clear) {
     return 0;
 }
 #endif
+
+// ================================================================== the two heads' first-layer dgrad as one contraction
+// (pn2_hip.h pn2_mlp_pair_dgrad_f32)
+extern "C" int pn2_mlp_pair_dgrad_f32(int rows, const pn2_mlp_layer* la, const float* dza, const pn2_mlp_layer* lb, const float* dzb,
+                                      const float* x, int64_t ldx, float* dx, int64_t lddx, const pn2_segments* segments,
+                                      int precision, void* stream) {
+    const int x16 = (precision & PN2_CHAIN_X_BF16) ? 1 : 0, s16 = (precision & PN2_CHAIN_STORE_BF16) ? 1 : 0;
+    const int dx16 = (precision & PN2_CHAIN_DX_BF16) ? 1 : 0;
+    precision &= ~(PN2_CHAIN_X_BF16 | PN2_CHAIN_STORE_BF16 | PN2_CHAIN_DX_BF16);
+    if (!la || !lb || !dza || !dzb || !dx || rows <= 0) return PN2_E_BADARG;
+    if (la->cin != lb->cin || la->cout != lb->cout || !la->has_bn || !lb->has_bn || la->relu != lb->relu || !la->y || !lb->y ||
+        !la->stats || !lb->stats || !la->weight || !lb->weight || la->cin % 4 || la->cout % BK)
+        return PN2_E_BADARG;
+    if (precision != PN2_PRECISION_F32 && precision != PN2_PRECISION_BF16) return PN2_E_BADARG;
+    if ((x16 || s16 || dx16) && (precision != PN2_PRECISION_BF16 || !s16)) return PN2_E_BADARG;
+    if (pick_tile(rows, la->cin, 1) != 128) return PN2_E_BADARG;      // the big-tile kernels only
+    if (!segs_valid(rows, segments, 1)) return PN2_E_BADARG;
+    const Segs S = make_segs(rows, segments);
+    const int cin = la->cin, cout = la->cout;
+    GemmArgs g{};
+    g.precision = precision;
+    g.A = plain(dza, cout, rows, cout);
+    g.A.p16 = s16, g.A.q = la->y, g.A.q16 = s16, g.A.ldq = cout, g.A.coef = la->stats, g.A.cstride = cout, g.A.relu = la->relu;
+    g.A2p = dzb, g.A2q = lb->y, g.A2coef = lb->stats;
+    g.B = plain(la->weight, cin, cout, cin);
+    g.B2p = lb->weight;
+    g.ksplit = cout;
+    g.M = rows, g.N = cin, g.K = 2 * cout;
+    g.C = dx, g.ldc = lddx, g.c16 = dx16, g.ey16 = x16;
+    if (la->in_stats && la->in_partial) {   // linked heads: the producing layer's BatchNorm-backward sums from the epilogue
+        if (!x) return PN2_E_BADARG;
+        g.partial = la->in_partial;
+        g.ey = x, g.ldey = ldx, g.ecoef = la->in_stats, g.erelu = la->in_relu;
+        g.pstride = cm_stride(rows, 128, S.nseg);
+    }
+    if (!(vec_ok(g.A) && vec_ok(g.B) && aligned16(dzb) && aligned16(lb->y) && aligned16(lb->weight))) return PN2_E_BADARG;
+    hipStream_t s = (hipStream_t)stream;
+    const int st16 = (g.A.p16 ? 1 : 0) | (g.c16 ? 4 : 0) | (g.ey16 ? 8 : 0);
+    if (st16) {
+        if (g.partial && !g.ey16) return PN2_E_BADARG;
+        switch (st16 | 8) {
+            case 9: return launch_gemm_tv<true, TR_DY, false, TR_PLAIN, EPI_STORE, 128, true, 1, true, NT, 9, true>(g, S, s, nullptr);
+            case 13: return launch_gemm_tv<true, TR_DY, false, TR_PLAIN, EPI_STORE, 128, true, 1, true, NT, 13, true>(g, S, s, nullptr);
+            default: return PN2_E_BADARG;
+        }
+    }
+    if (precision == PN2_PRECISION_BF16)
+        return launch_gemm_tv<true, TR_DY, false, TR_PLAIN, EPI_STORE, 128, true, 1, true, NT, 0, true>(g, S, s, nullptr);
+    return launch_gemm_tv<true, TR_DY, false, TR_PLAIN, EPI_STORE, 128, true, 1, false, NT, 0, true>(g, S, s, nullptr);
+}

@@ -299,6 +299,10 @@ struct GemmArgs {
     int precision;        // host side only: PN2_PRECISION_* of the 128-tile contraction (travels with the call, no global state)
     int accumulate;       // EPI_STORE: C += result (PN2_CHAIN_ACCUMULATE_DX): the accumulators START from C -- the loads
                           // travel with the first K-tile's instead of forming a read-modify-write chain in the epilogue
+    // DUAL kernels (the dgrad of two heads on the same input, dX = dY_a W_a + dY_b W_b as ONE contraction over K = 2 cout):
+    // from contraction index ksplit on, the operands come from the second head -- same shapes, strides and ReLU flag
+    const float *A2p, *A2q, *A2coef, *B2p;
+    int ksplit;
 };
 
 // TILE = 128: four waves own 64 x 64 each (2 x 2 MFMA accumulators); TILE = 64: 32 x 32 each (one accumulator),
@@ -469,7 +473,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[N
 // pins 2 * 64 * 64 * K flops to one unit's matrix cores: 1.7 us per K-tile with four teams on it, tools/diag_coop.py).
 // ST (bf16 mode with bfloat16 storage, pn2_hip.h PN2_CHAIN_STORE_BF16): bit 0 the A operand's rows, bit 1 the B operand's rows,
 // bit 2 C (and what ACC reads of it), bit 3 the epilogue's ey rows are __bf16.
-template <bool A_T, int A_KIND, bool B_T, int B_KIND, int EPI, int TILE, bool VEC, int TEAMS, bool BF16, bool ACC, bool COH, int NTT, int ST, class TAB>
+template <bool A_T, int A_KIND, bool B_T, int B_KIND, int EPI, int TILE, bool VEC, int TEAMS, bool BF16, bool ACC, bool COH, int NTT, int ST,
+          bool DUAL = false, class TAB = SegTable>
 __device__ __forceinline__ void gemm_body(const GemmArgs& g0, const TAB& st, const int BX, const int BY, const int BZ,
                                           float* __restrict__ lds) {
     static_assert(NTT == NT || (NTT == 64 && TILE == 32 && TEAMS > 1), "single-wavefront teams are for the 32-tile");
@@ -493,6 +498,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g0, const TAB& st, con
         g.A.rows = g.M = rb.row_end;
     }
     if (g.A.coef) g.A.coef += (long long)seg * ST_ROWS * g.A.cstride;
+    if (DUAL && g.A2coef) g.A2coef += (long long)seg * ST_ROWS * g.A.cstride;
     if (g.B.coef) g.B.coef += (long long)seg * ST_ROWS * g.B.cstride;
     if (EPI == EPI_STORE && g.ecoef) g.ecoef += (long long)seg * ST_ROWS * g.N;
     static_assert(TEAMS == 1 || TILE == 64 || TILE == 32, "teams are for the small-problem tiles");
@@ -569,10 +575,17 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g0, const TAB& st, con
     PN2_GEMM_STAMP(2);
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        const int knext = k_begin + (kt + 1) * BK;
+        int knext = k_begin + (kt + 1) * BK;
+        Operand da_ = g.A, db_ = g.B;        // DUAL: the operands the NEXT tile is read from -- the second head's from ksplit on
+        if (DUAL && knext >= g.ksplit) {
+            da_.p = g.A2p, da_.q = g.A2q, da_.coef = g.A2coef, db_.p = g.B2p;
+            knext -= g.ksplit;
+        }
+        const Operand& na = DUAL ? da_ : g.A;
+        const Operand& nb = DUAL ? db_ : g.B;
         if (kt + 1 < nk) {
-            sa.fetch(g.A, m0, knext);
-            sb.fetch(g.B, n0, knext);
+            sa.fetch(na, m0, knext);
+            sb.fetch(nb, n0, knext);
         }
         const float* a = As[cur] + wm * WT + l31;
         const float* b = Bs[cur] + wn * WT + l31;
@@ -600,8 +613,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g0, const TAB& st, con
                 for (int j = 0; j < NI; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
             if (kt + 1 < nk) {
-                sa.commit(g.A, As[cur ^ 1], m0, knext);
-                sb.commit(g.B, Bs[cur ^ 1], n0, knext);
+                sa.commit(na, As[cur ^ 1], m0, knext);
+                sb.commit(nb, Bs[cur ^ 1], n0, knext);
             }
         } else
 #pragma unroll
@@ -622,8 +635,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g0, const TAB& st, con
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
             }
             if (kt + 1 < nk) {
-                sa.commit_pass(g.A, As[cur ^ 1], m0, knext, q);
-                sb.commit_pass(g.B, Bs[cur ^ 1], n0, knext, q);
+                sa.commit_pass(na, As[cur ^ 1], m0, knext, q);
+                sb.commit_pass(nb, Bs[cur ^ 1], n0, knext, q);
             }
         }
         __syncthreads();
@@ -654,11 +667,11 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g0, const TAB& st, con
 
 // One tile per workgroup: the launch grid is the tile grid.
 template <bool A_T, int A_KIND, bool B_T, int B_KIND, int EPI, int TILE, bool VEC, int TEAMS, bool BF16 = false, bool ACC = false,
-          int NTT = NT, int ST = 0>
+          int NTT = NT, int ST = 0, bool DUAL = false>
 __global__ __launch_bounds__(NTT * TEAMS, (NTT == 64 ? 4 : TEAMS > 1 ? 1 : (EPI == EPI_STORE ? PN2_DGRAD_OCC : 3))) void gemm_kernel(const GemmArgs g0,
                                                                                                                         const SegTable st) {
     __shared__ __attribute__((aligned(16))) float lds[TEAMS * 4 * BK * (TILE + 4)];
-    gemm_body<A_T, A_KIND, B_T, B_KIND, EPI, TILE, VEC, TEAMS, BF16, ACC, false, NTT, ST>(g0, st, (int)blockIdx.x, (int)blockIdx.y,
+    gemm_body<A_T, A_KIND, B_T, B_KIND, EPI, TILE, VEC, TEAMS, BF16, ACC, false, NTT, ST, DUAL>(g0, st, (int)blockIdx.x, (int)blockIdx.y,
                                                                                       (int)blockIdx.z, lds);
 }
 

@@ -252,6 +252,8 @@ class _ChainFn(torch.autograd.Function):
                   deferred, _coop(dev), ws.data_ptr(), ws.numel(), _hip.stream_ptr(), nbytes=nbytes, flops=flops)
         if emit is not None:
             link.handle["partial"] = emit
+        if getattr(ctx, "keep_layer0", False):        # _ChainPairFn: the fused first-layer dgrad of the two heads needs them
+            ctx.kept = {"dz0": sa, "scratch": sb, "arr": arr, "x": x, "flags": ctx.precision, "seg": (seg_ptr, seg_keep), "ws": ws}
         return (dx, None, *grads)
 
 
@@ -337,6 +339,8 @@ class _ChainPairFn(torch.autograd.Function):
     def backward(ctx, da, db):
         a, b, n_a = ctx.subs
         need = ctx.needs_input_grad
+        if need[0] and _ChainPairFn._fusable(a, b):
+            return _ChainPairFn._backward_fused(ctx, a, b, n_a, da, db)
         a.needs_input_grad = (need[0], False) + tuple(need[4:4 + n_a])
         b.needs_input_grad = (need[0], False) + tuple(need[4 + n_a:])
         a.dx_is_complete = False                       # the second chain adds to it: only that one can do the producer's sums
@@ -345,6 +349,65 @@ class _ChainPairFn(torch.autograd.Function):
         gb = _ChainFn.backward(b, db)
         ctx.subs = None
         return (ga[0], None, None, None) + tuple(ga[2:]) + tuple(gb[2:])
+
+
+def _pair_fusable(a, b):
+    """Both chains: two layers, a BatchNorm after the first, equal shapes, big enough for the 128-row tiles (the conditions
+    of pn2_mlp_pair_dgrad_f32), the same row storage."""
+    if os.environ.get("PN2_NO_PAIR_DGRAD"):
+        return False
+    ma, mb = a.meta, b.meta
+    if len(ma["layers"]) != 2 or len(mb["layers"]) != 2 or ma["pool_k"] != 1 or mb["pool_k"] != 1:
+        return False
+    la, lb = a.arr[0], b.arr[0]
+    rows, cin = a.dims
+    return (bool(la.has_bn) and bool(lb.has_bn) and int(la.cin) == int(lb.cin) == 128 and int(la.cout) == int(lb.cout)
+            and int(la.cout) % 16 == 0 and int(la.relu) == int(lb.relu) and rows >= 12288 and a.dims == b.dims
+            and a.precision == b.precision and ma.get("seg_off") == mb.get("seg_off") and ma["training"] and mb["training"])
+
+
+def _pair_backward_fused(ctx, a, b, n_a, da, db):
+    """Both chains' backward passes without their first-layer dgrad, then dx = dY_a W_a + dY_b W_b as ONE contraction
+    (include/pn2_hip.h: pn2_mlp_pair_dgrad_f32), which also leaves the producer's BatchNorm-backward sums."""
+    lib = _hip.lib()
+    need = ctx.needs_input_grad
+    a.needs_input_grad = (False, False) + tuple(need[4:4 + n_a])
+    b.needs_input_grad = (False, False) + tuple(need[4 + n_a:])
+    a.keep_layer0 = b.keep_layer0 = True
+    ga = _ChainFn.backward(a, da)
+    gb = _ChainFn.backward(b, db)
+    ka, kb = a.kept, b.kept
+    x = ka["x"]
+    rows, cin0 = a.dims
+    dev = x.device
+    dx = torch.empty(rows, cin0, dtype=x.dtype, device=dev)
+    flags = a.precision
+    store16 = bool(flags & _hip.CHAIN_STORE_BF16)
+    if store16:
+        flags |= (_hip.CHAIN_X_BF16 if x.dtype == torch.bfloat16 else 0) | (_hip.CHAIN_DX_BF16 if dx.dtype == torch.bfloat16 else 0)
+    la, lb = ka["arr"][0], kb["arr"][0]
+    link = getattr(a, "link", None)
+    emit = None
+    if link is not None and not link.handle.get("shared") and not os.environ.get("PN2_NO_LINK_SUMS"):
+        r_, c_ = ctypes.c_int32(0), ctypes.c_int32(0)
+        nb = lib.pn2_mlp_link_partial_bytes(rows, cin0, a.nseg, ctypes.byref(r_), ctypes.byref(c_))
+        emit = (torch.empty(nb, dtype=torch.uint8, device=dev), int(r_.value), int(c_.value))
+        la.in_partial = emit[0].data_ptr()
+    else:
+        la.in_partial = None
+    cout = int(la.cout)
+    _hip.call("mlp_pair_dgrad", lib.pn2_mlp_pair_dgrad_f32, rows, ctypes.byref(la), ka["dz0"].data_ptr(), ctypes.byref(lb),
+              kb["dz0"].data_ptr(), x.data_ptr(), x.stride(0), dx.data_ptr(), cin0, ka["seg"][0], flags, _hip.stream_ptr(),
+              nbytes=4 * rows * (cin0 + 4 * cout), flops=4 * rows * cin0 * cout)
+    if emit is not None:
+        link.handle["partial"] = emit
+    ctx.subs = None
+    a.kept = b.kept = None
+    return (dx, None, None, None) + tuple(ga[2:]) + tuple(gb[2:])
+
+
+_ChainPairFn._fusable = staticmethod(_pair_fusable)
+_ChainPairFn._backward_fused = staticmethod(_pair_backward_fused)
 
 
 class batched_counters:

@@ -411,6 +411,18 @@ int pn2_mlp_chain_bwd_f32(const float *x, int64_t ldx, int rows, const pn2_mlp_l
 size_t pn2_mlp_link_partial_bytes(int rows, int cin, int nseg, int32_t *block_rows, int32_t *chunks_per_block);
 int pn2_mlp_reduce_wgrad(const pn2_wgrad_task *tasks, int n, void *stream);
 
+/* The first-layer dgrad of TWO chains that read the same rows (the two prediction heads on the backbone features,
+ * PointNet2.py:128-129) as ONE contraction: dx = dY_a W_a + dY_b W_b over K = 2 cout -- one launch, one prologue and epilogue,
+ * no read-modify-write of dx in between (pn2_mlp_chain_bwd_f32 with dx = NULL has run for both chains: their layers[0]
+ * hold y, stats with the backward coefficients and weight; dza / dzb = the gradient rows each call left in its scratch_a,
+ * i.e. the gradient with respect to relu(bn(y)) of that layer).  la / lb: cin, cout (a multiple of 16), has_bn, relu equal;
+ * rows large enough for the 128-row tiles.  Linked heads: la->in_stats / in_relu / in_partial as for the chains (x = the
+ * producer's rows), and the producer's BatchNorm-backward sums are left behind by the epilogue.  `precision` and the
+ * PN2_CHAIN_{X,STORE,DX}_BF16 flags as for pn2_mlp_chain_bwd_f32. */
+int pn2_mlp_pair_dgrad_f32(int rows, const pn2_mlp_layer *la, const float *dza, const pn2_mlp_layer *lb, const float *dzb,
+                           const float *x, int64_t ldx, float *dx, int64_t lddx, const pn2_segments *segments, int precision,
+                           void *stream);
+
 /* Feature propagation with the first convolution HOISTED in front of the interpolation   (blocks.py:194-215)
  *
  * Where a feature-propagation level has no skip connection (fp1: points1 = None, PointNet2.py:156) its first layer is

@@ -300,3 +300,54 @@ def test_hoisted_set_abstraction_with_row_segments():
         if k == "grad:mlp_convs.0.bias":
             continue
         _close(res[True][k], res[False][k], 3e-5, f"hoisted vs plain with segments: {k}")
+
+
+@pytest.mark.parametrize("linked,segments,precision", [(True, False, "f32"), (True, True, "f32"), (False, False, "f32"),
+                                                       (True, False, "bf16")])
+def test_pair_dgrad_as_one_contraction(linked, segments, precision):
+    """The two heads' first-layer dgrad as ONE contraction over K = 2 * 128 (pn2_mlp_pair_dgrad_f32) against the two launches
+    of which the second accumulates (PN2_NO_PAIR_DGRAD=1): input gradient, the producer's gradients (its BatchNorm-backward sums
+    come out of the fused launch's epilogue), the heads' own gradients."""
+    import torch.nn as nn
+    helpers.load_pkg()
+    from pn2_amd import _hip, mlp
+
+    def build():
+        torch.manual_seed(0)
+        mk = lambda ci, co, bn=True: (nn.Conv1d(ci, co, 1).cuda(), nn.BatchNorm1d(co).cuda().train() if bn else None, bn)
+        return [mk(128, 128), mk(128, 128)], [mk(128, 128), mk(128, 2, False)], [mk(128, 128), mk(128, 3, False)]
+
+    rows = 20000
+    seg = [0, 7000, 7000 + 5120, rows] if segments else None
+    x0 = torch.randn(rows, 128, device="cuda")
+    res = {}
+    old = mlp.GEMM_PRECISION
+    mlp.GEMM_PRECISION = precision
+    try:
+        for mode, e in (("fused", {}), ("two_launches", {"PN2_NO_PAIR_DGRAD": 1})):
+            trunk, ha, hb = build()
+            x = x0.clone().requires_grad_(True)
+            names = []
+            orig = _hip.call
+
+            def spy(name, fn, *a, **k):
+                names.append(name)
+                return orig(name, fn, *a, **k)
+
+            _hip.call = spy
+            try:
+                with env(**e):
+                    feats = mlp.chain_rows(x, trunk, seg_off=seg, lazy_out=True) if linked else x
+                    a, b = mlp.chain_pair_rows(feats, ha, hb, seg_off=seg)
+                    ((a * a).sum() + (b * torch.arange(3, device="cuda")).sum()).backward()
+            finally:
+                _hip.call = orig
+            assert ("mlp_pair_dgrad" in names) == (mode == "fused")
+            chains = (trunk, ha, hb) if linked else (ha, hb)
+            params = [p for chain in chains for conv, bn, _ in chain for p in ([conv.weight] + ([bn.weight, bn.bias] if bn else [conv.bias]))]
+            res[mode] = [x.grad.clone()] + [p.grad.clone() for p in params]
+    finally:
+        mlp.GEMM_PRECISION = old
+    tol = 2e-5 if precision == "f32" else 2e-2
+    for g, h in zip(res["fused"], res["two_launches"]):
+        assert float((g.float() - h.float()).norm()) <= tol * float(h.float().norm()) + 1e-7, (float((g - h).norm()), float(h.norm()))
