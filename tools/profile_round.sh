@@ -20,6 +20,11 @@ PN2_NO_COOP=1 timeout -k 10 300 python bench.py --no-cpu-baseline > $O/bench_no_
 PN2_COOP_MAX_ROWS=10000 timeout -k 10 300 python bench.py --no-cpu-baseline > $O/bench_coop_all_levels.json 2>> $O/bench.err
 PN2_NO_TILE32=1 PN2_NO_COOP=1 timeout -k 10 300 python bench.py --no-cpu-baseline > $O/bench_no_tile32.json 2>> $O/bench.err
 PN2_BF16_STORAGE=0 timeout -k 10 300 python bench.py --dtype bf16 --no-cpu-baseline > $O/bench_bf16_fp32_rows.json 2>> $O/bench.err
+PN2_NO_HOIST=1 timeout -k 10 300 python bench.py --no-cpu-baseline > $O/bench_no_hoist.json 2>> $O/bench.err
+PN2_NO_HOIST=1 timeout -k 10 300 python bench.py --mode rasterized --no-cpu-baseline > $O/bench_rasterized_no_hoist.json 2>> $O/bench.err
+PN2_NO_HOIST_GROUP=1 timeout -k 10 300 python bench.py --mode rasterized --no-cpu-baseline > $O/bench_rasterized_no_group_hoist.json 2>> $O/bench.err
+PN2_NO_HOIST=1 timeout -k 10 300 python bench.py --dtype bf16 --no-cpu-baseline > $O/bench_bf16_no_hoist.json 2>> $O/bench.err
+PN2_NO_PAIR_DGRAD=1 timeout -k 10 300 python bench.py --no-cpu-baseline > $O/bench_no_pair_dgrad.json 2>> $O/bench.err
 PN2_DIST_BACKEND=gloo timeout -k 10 300 python bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_gloo2_selfspawn.json 2>> $O/bench.err
 echo "bench variants done"
 fi
@@ -41,5 +46,8 @@ timeout -k 10 300 python tools/bench_datapath.py > $O/bench_datapath.json 2>> $O
 timeout -k 10 300 python tools/bench_serialization.py > $O/bench_serialization.json 2>> $O/bench.err
 timeout -k 10 300 python tools/bench_ptv3_attention.py > $O/bench_ptv3_attention.json 2>> $O/bench.err
 timeout -k 10 300 python tools/bench_chain.py --reps 50 > $O/bench_chain.txt 2>> $O/bench.err
+if [ -f extracting-tree-morphology-from-point-clouds_amd/build_diag/libpn2hip_gemm_diag.so ]; then   # tools/build_diag_gemm.sh
+  timeout -k 10 200 python tools/diag_gemm.py 2>/dev/null | grep -v amdgpu.ids > $O/diag_gemm.txt || true
+fi
 echo "secondary benches done"
 ls -la $O
