@@ -566,6 +566,27 @@ int pn2_serialize_encode_i64(const int32_t *grid_coord, int64_t gs, int64_t gc, 
 int pn2_serialize_decode_i64(const int64_t *codes, long long N, int depth, int order, int64_t *out_grid,
                              int64_t *out_batch, void *stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * PointTransformerV3 conditional positional encoding   replaces the spconv.SubMConv3d(channels, channels, kernel_size=3,
+ *   bias=True) in front of every Block, Modules/PointTransformerV3/blocks.py:561-568, on the voxels of Point.sparsify
+ *   (:153-190: indices = [batch, grid_coord]).  spconv is absent here; the operator built is its definition -- the dense
+ *   cross-correlation conv3d(padding = 1) of the voxel grid evaluated at the active voxels, inactive voxels contributing zeros:
+ *       out[i] = bias + sum_{d in {-1,0,1}^3} W[d] feat[j(i, d)],   j(i, d) = the active voxel of i's cloud at grid_coord[i] + d.
+ *
+ * pn2_ptv3_subm_neighbors_i32   nbr [N][27] int32 = j(i, d) or -1, offset index d = (dx + 1) * 9 + (dy + 1) * 3 + (dz + 1) for
+ *   grid_coord = (x, y, z).  batch: device int64 [N] cloud ids 0..65535 (NULL: one cloud); grid_coord: device int32 [N][3],
+ *   0 <= coordinate <= 65533 (a voxel outside gets no neighbours and PN2_STATUS_BAD_INDEX); duplicate voxels are represented by
+ *   their lowest index.  The table is what the Blocks of one stage share (spconv's indice_key).
+ *   workspace: pn2_ptv3_subm_workspace_bytes(N) (the hash table; contents irrelevant on entry).
+ * pn2_ptv3_subm_conv_f32        feat [N][C_in] (row stride ldf, a multiple of 4), weight [27][C_in][C_out] (offset-major: the
+ *   mirror permutes spconv's [C_out][3][3][3][C_in] parameter), bias [C_out] or NULL -> out [N][C_out] (row stride ldo).
+ *   C_in a multiple of 16, C_out of 32.  fp32 (v_mfma_f32_32x32x2_f32).  Forward only. */
+size_t pn2_ptv3_subm_workspace_bytes(int N);
+int pn2_ptv3_subm_neighbors_i32(const int64_t *batch, const int32_t *grid_coord, int N, int32_t *nbr, void *workspace,
+                                size_t workspace_bytes, int32_t *status, void *stream);
+int pn2_ptv3_subm_conv_f32(const float *feat, int64_t ldf, const int32_t *nbr, const float *weight, const float *bias, int N,
+                           int Cin, int Cout, float *out, int64_t ldo, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
