@@ -57,12 +57,8 @@ __global__ __launch_bounds__(256) void voxel_insert_kernel(const long long* __re
     unsigned h = hash64(key) & mask;
     for (;;) {   // terminates: the table has at least 2 N slots
         const u64 old = atomicCAS(keys + h, kEmpty, key);
-        if (old == kEmpty) {
-            vals[h] = i;
-            return;
-        }
-        if (old == key) {   // a duplicate voxel: the lowest index represents the cell (the reference's voxels are unique)
-            atomicMin(vals + h, i);
+        if (old == kEmpty || old == key) {   // the slot is this voxel's cell; duplicate voxels: the lowest index represents the cell
+            atomicMin(vals + h, i);          // (the reference's voxels are unique; vals starts at 0x7F7F7F7F)
             return;
         }
         h = (h + 1) & mask;
@@ -202,6 +198,129 @@ __global__ __launch_bounds__(256) void subm_conv_kernel(const float* __restrict_
     }
 }
 
+// ---- the same contraction with the rows COMPACTED per offset ------------------------------------------------------------------
+// At the occupancy of real plots (2-13 of the 27 neighbours present) a 128-voxel tile keeps nearly every offset slab although only
+// 7-47 % of its rows have that neighbour, and the kernel above multiplies the zero rows too.  Here a tile's voxels that HAVE a
+// neighbour at offset d are compacted into blocks of 32 (ballots over the tile's neighbour table in LDS), and a block is one
+// wavefront's item: it gathers the block's 32 neighbour rows through a private LDS buffer (K-major, double buffered, no
+// workgroup barrier), takes the offset's weight fragments straight from the L2-resident slab, and adds its 32 x CT products to an
+// LDS copy of the output tile with ds_add_f32 (an output row receives at most one product row per offset; items of different
+// offsets may meet in a row, hence the atomic -- the order of those <= 27 additions is not fixed, so the result may differ in the
+// last bits from run to run, as every float-atomic reduction in this library).  The four wavefronts take items round-robin.
+// Executed matrix work: ~27-33 blocks per tile instead of 95-108 at 2-5 present neighbours (tools/bench_ptv3_cpe.py).
+__device__ __forceinline__ int nth_set_bit(u64 m, int n) {   // position of the n-th (0-based) set bit; n < popcount(m)
+    int pos = 0;
+#pragma unroll
+    for (int w = 32; w > 0; w >>= 1) {
+        const int c = __popcll((m >> pos) & ((1ull << w) - 1ull));
+        if (n >= c) {
+            n -= c;
+            pos += w;
+        }
+    }
+    return pos;
+}
+__device__ __forceinline__ void wave_lds_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+constexpr int ALD = 36;   // row pitch (floats) of a wavefront's [k][32 rows] staging buffer
+
+template <int CT>   // columns per workgroup: 32 or 64
+__global__ __launch_bounds__(256) void subm_conv_compact_kernel(const float* __restrict__ feat, long long ldf,
+                                                                const int32_t* __restrict__ nbr, const float* __restrict__ weight,
+                                                                const float* __restrict__ bias, int N, int Cin, int Cout,
+                                                                float* __restrict__ out, long long ldo) {
+    constexpr int NJ = CT / 32, OLD = CT + 4;
+    __shared__ __attribute__((aligned(16))) float O[CT_ROWS * OLD];
+    __shared__ int s_nbr[CT_ROWS * 27];
+    __shared__ __attribute__((aligned(16))) float Aw[4][2][CBK * ALD];
+    __shared__ int s_rows[4][32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+    const int m0 = blockIdx.x * CT_ROWS, n0 = blockIdx.y * CT;
+    for (int e = tid; e < CT_ROWS * 27; e += 256) {
+        const int r = e / 27;
+        s_nbr[e] = m0 + r < N ? nbr[27ll * m0 + e] : -1;
+    }
+    for (int e = tid; e < CT_ROWS * CT; e += 256) {
+        const int r = e / CT, c = e - r * CT;
+        O[r * OLD + c] = bias ? bias[n0 + c] : 0.0f;
+    }
+    __syncthreads();
+    const int ktiles = Cin / CBK;
+    int item = 0;   // running (offset, block) item number of the tile: wavefront w takes items w, w + 4, ...
+    for (int d = 0; d < 27; ++d) {
+        const u64 mlo = __ballot(s_nbr[lane * 27 + d] >= 0), mhi = __ballot(s_nbr[(lane + 64) * 27 + d] >= 0);
+        const int clo = __popcll(mlo), count = clo + __popcll(mhi);
+        const int nblk = (count + 31) >> 5;
+        const float* wd = weight + (long long)d * Cin * Cout + n0;
+        for (int blk = 0; blk < nblk; ++blk, ++item) {
+            if ((item & 3) != wave) continue;   // wave-uniform
+            // this lane's compacted row (both half-wavefronts hold the same 32 rows)
+            const int q = 32 * blk + l31;
+            const bool valid = q < count;
+            int row = 0;
+            if (valid) row = q < clo ? nth_set_bit(mlo, q) : 64 + nth_set_bit(mhi, q - clo);
+            const int j = valid ? s_nbr[row * 27 + d] : -1;
+            if (lane < 32) s_rows[wave][lane] = valid ? row : -1;
+            // staging roles: chunk c = lane (rows 0..15) and lane + 64 (rows 16..31), four consecutive k each
+            const int jA = __shfl(j, lane >> 2, 64), jB = __shfl(j, 16 + (lane >> 2), 64);
+            const int ka = 4 * (lane & 3);
+            f32x16 acc[NJ];
+#pragma unroll
+            for (int jn = 0; jn < NJ; ++jn)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[jn][r] = 0.0f;
+            float4 va = jA >= 0 ? *(const float4*)(feat + (long long)jA * ldf + ka) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 vb = jB >= 0 ? *(const float4*)(feat + (long long)jB * ldf + ka) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int kt = 0; kt < ktiles; ++kt) {
+                float* A = Aw[wave][kt & 1];
+                {
+                    float* dst = A + ka * ALD + (lane >> 2);
+                    dst[0] = va.x, dst[ALD] = va.y, dst[2 * ALD] = va.z, dst[3 * ALD] = va.w;
+                    dst[16] = vb.x, dst[ALD + 16] = vb.y, dst[2 * ALD + 16] = vb.z, dst[3 * ALD + 16] = vb.w;
+                }
+                const int k0 = kt * CBK;
+                // the weight fragments of this K-tile (L2-resident slab) and the next tile's rows: all loads in flight together
+                float bw[CBK / 2][NJ];
+#pragma unroll
+                for (int s2 = 0; s2 < CBK / 2; ++s2)
+#pragma unroll
+                    for (int jn = 0; jn < NJ; ++jn) bw[s2][jn] = wd[(long long)(k0 + 2 * s2 + half) * Cout + 32 * jn + l31];
+                if (kt + 1 < ktiles) {
+                    va = jA >= 0 ? *(const float4*)(feat + (long long)jA * ldf + k0 + CBK + ka) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    vb = jB >= 0 ? *(const float4*)(feat + (long long)jB * ldf + k0 + CBK + ka) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                wave_lds_sync();
+#pragma unroll
+                for (int s2 = 0; s2 < CBK / 2; ++s2) {
+                    const float av = A[(2 * s2 + half) * ALD + l31];
+#pragma unroll
+                    for (int jn = 0; jn < NJ; ++jn) acc[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bw[s2][jn], acc[jn], 0, 0, 0);
+                }
+                // (the other buffer is written next; this one again two tiles later, after this tile's reads were issued in order)
+            }
+            wave_lds_sync();
+            // add the block's products to the output tile: accumulator row p = (r & 3) + 8 (r >> 2) + 4 half -> voxel s_rows[p]
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int orow = s_rows[wave][(r & 3) + 8 * (r >> 2) + 4 * half];
+                if (orow >= 0) {
+#pragma unroll
+                    for (int jn = 0; jn < NJ; ++jn) atomicAdd(&O[orow * OLD + 32 * jn + l31], acc[jn][r]);
+                }
+            }
+            wave_lds_sync();   // s_rows is rewritten by this wavefront's next item
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < CT_ROWS * CT; e += 256) {
+        const int r = e / CT, c = e - r * CT;
+        if (m0 + r < N) out[(long long)(m0 + r) * ldo + n0 + c] = O[r * OLD + c];
+    }
+}
+
 inline size_t table_slots(int N) {
     size_t t = 1024;
     while (t < 2 * (size_t)N) t <<= 1;
@@ -239,6 +358,22 @@ extern "C" int pn2_ptv3_subm_conv_f32(const float* feat, int64_t ldf, const int3
         ldo < Cout || ((uintptr_t)feat & 15) || ((uintptr_t)weight & 15))
         return PN2_E_BADARG;
     hipStream_t s = (hipStream_t)stream;
+    // rows compacted per offset from 128 input channels on (measured at 3.7 present neighbours, 1 M voxels: C = 128 7.0 -> 5.0 ms;
+    // C = 64 2.06 -> 2.00; C = 32 0.68 -> 0.92: an item's per-K-tile round trips are not amortised by narrow rows);
+    // PN2_CPE_DENSE_TILES=1 / PN2_CPE_COMPACT=1 force either kernel (A/B aid)
+    if ((Cin >= 128 || getenv("PN2_CPE_COMPACT")) && !getenv("PN2_CPE_DENSE_TILES")) {
+        const int ctc = Cout % 64 == 0 ? 64 : 32;
+        const dim3 gridc(pn2::ceil_div(N, CT_ROWS), Cout / ctc);
+        const double fl = 2.0 * 27.0 * N * (double)Cin * Cout, by = 4.0 * N * (27.0 + Cin + Cout) + 4.0 * 27.0 * Cin * Cout;
+        if (ctc == 64)
+            PN2_LAUNCH("ptv3_subm_conv", by, fl, (subm_conv_compact_kernel<64>), gridc, dim3(256), s, feat, (long long)ldf, nbr, weight, bias,
+                       N, Cin, Cout, out, (long long)ldo);
+        else
+            PN2_LAUNCH("ptv3_subm_conv", by, fl, (subm_conv_compact_kernel<32>), gridc, dim3(256), s, feat, (long long)ldf, nbr, weight, bias,
+                       N, Cin, Cout, out, (long long)ldo);
+        PN2_LAUNCH_CHECK();
+        return 0;
+    }
     const int ct = Cout % 128 == 0 ? 128 : (Cout % 64 == 0 ? 64 : 32);
     const dim3 grid(pn2::ceil_div(N, CT_ROWS), Cout / ct);
     const double flops = 2.0 * 27.0 * N * (double)Cin * Cout;   // upper bound: the dense stencil (skipped slabs do no work)

@@ -54,7 +54,14 @@ def test_oracle_is_the_dense_conv3d_at_the_active_voxels():
     (4000, 2, 50, 128, 128, 7),      # 128-column tiles; seven duplicate voxels (lowest index represents the cell)
     (130, 1, 400, 16, 256, 0),       # isolated voxels: almost every offset slab skipped; two column tiles
 ])
-def test_subm_conv_matches_oracle(n, clouds, extent, cin, cout, dup):
+@pytest.mark.parametrize("kernel", ["default", "compact", "dense"])
+def test_subm_conv_matches_oracle(n, clouds, extent, cin, cout, dup, kernel, monkeypatch):
+    """Both kernels at every shape: whole 128-voxel tiles per offset (default below 128 input channels) and the rows compacted per
+    offset (default from 128 on)."""
+    if kernel == "compact":
+        monkeypatch.setenv("PN2_CPE_COMPACT", "1")
+    elif kernel == "dense":
+        monkeypatch.setenv("PN2_CPE_DENSE_TILES", "1")
     helpers.load_pkg()
     from oracle import ptv3_cpe_port as P
     from pn2_amd.PointTransformerV3 import cpe
