@@ -1,0 +1,82 @@
+"""The PointTransformerV3 backbone with the reference's constructor, module tree and parameter names
+(Modules/PointTransformerV3/PointTransformerV3.py:261-460), so that a state dict of the reference's `backbone` loads: embedding
+(5 x 5 x 5 stem) -> five encoder stages (serialized pooling, Blocks) -> four decoder stages (serialized unpooling, Blocks).
+Built from blocks.py (which says what is this library's kernel and what is a plain library call).  INFERENCE ONLY, PARITY
+UNPINNED (see blocks.py); the repository's configuration -- enable_flash = enable_rpe = False, no PDNorm -- is what is built,
+the other options raise."""
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+from .blocks import Block, Embedding, Point, PointModule, PointSequential, SerializedPooling, SerializedUnpooling
+
+
+class PointTransformerV3(PointModule):
+    def __init__(self, in_channels=6, order=("z", "z-trans", "hilbert", "hilbert-trans"), stride=(2, 2, 2, 2),
+                 enc_depths=(2, 2, 2, 6, 2), enc_channels=(32, 64, 128, 256, 512), enc_num_head=(2, 4, 8, 16, 32),
+                 enc_patch_size=(1024, 1024, 1024, 1024, 1024), dec_depths=(2, 2, 2, 2), dec_channels=(64, 64, 128, 256),
+                 dec_num_head=(4, 4, 8, 16), dec_patch_size=(1024, 1024, 1024, 1024), mlp_ratio=4, qkv_bias=True, qk_scale=None,
+                 attn_drop=0.0, proj_drop=0.0, drop_path=0.3, pre_norm=True, shuffle_orders=True, enable_rpe=False,
+                 enable_flash=False, upcast_attention=False, upcast_softmax=False, cls_mode=False, pdnorm_bn=False,
+                 pdnorm_ln=False, pdnorm_decouple=True, pdnorm_adaptive=False, pdnorm_affine=True,
+                 pdnorm_conditions=("ScanNet", "S3DIS", "Structured3D")):
+        super().__init__()
+        if pdnorm_bn or pdnorm_ln:
+            raise NotImplementedError("PDNorm is not built (the repository's model uses plain BatchNorm1d / LayerNorm)")
+        self.num_stages = len(enc_depths)
+        self.order = [order] if isinstance(order, str) else order
+        self.cls_mode, self.shuffle_orders = cls_mode, shuffle_orders
+        assert self.num_stages == len(stride) + 1 == len(enc_channels) == len(enc_num_head) == len(enc_patch_size)
+        assert self.cls_mode or self.num_stages == len(dec_depths) + 1 == len(dec_channels) + 1 == len(dec_num_head) + 1 \
+            == len(dec_patch_size) + 1
+        bn_layer = partial(nn.BatchNorm1d, eps=1e-3, momentum=0.01)
+        ln_layer = nn.LayerNorm
+        act_layer = nn.GELU
+        block = partial(Block, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop, proj_drop=proj_drop,
+                        norm_layer=ln_layer, act_layer=act_layer, pre_norm=pre_norm, enable_rpe=enable_rpe, enable_flash=enable_flash,
+                        upcast_attention=upcast_attention, upcast_softmax=upcast_softmax)
+        self.embedding = Embedding(in_channels=in_channels, embed_channels=enc_channels[0], norm_layer=bn_layer, act_layer=act_layer)
+
+        enc_drop_path = [x.item() for x in torch.linspace(0, drop_path, sum(enc_depths))]
+        self.enc = PointSequential()
+        for s in range(self.num_stages):
+            dp = enc_drop_path[sum(enc_depths[:s]):sum(enc_depths[:s + 1])]
+            enc = PointSequential()
+            if s > 0:
+                enc.add(SerializedPooling(in_channels=enc_channels[s - 1], out_channels=enc_channels[s], stride=stride[s - 1],
+                                          norm_layer=bn_layer, act_layer=act_layer), name="down")
+            for i in range(enc_depths[s]):
+                enc.add(block(channels=enc_channels[s], num_heads=enc_num_head[s], patch_size=enc_patch_size[s], drop_path=dp[i],
+                              order_index=i % len(self.order), cpe_indice_key=f"stage{s}"), name=f"block{i}")
+            if len(enc) != 0:
+                self.enc.add(module=enc, name=f"enc{s}")
+
+        if not self.cls_mode:
+            dec_drop_path = [x.item() for x in torch.linspace(0, drop_path, sum(dec_depths))]
+            self.dec = PointSequential()
+            dec_channels = list(dec_channels) + [enc_channels[-1]]
+            for s in reversed(range(self.num_stages - 1)):
+                dp = dec_drop_path[sum(dec_depths[:s]):sum(dec_depths[:s + 1])]
+                dp.reverse()
+                dec = PointSequential()
+                dec.add(SerializedUnpooling(in_channels=dec_channels[s + 1], skip_channels=enc_channels[s],
+                                            out_channels=dec_channels[s], norm_layer=bn_layer, act_layer=act_layer), name="up")
+                for i in range(dec_depths[s]):
+                    dec.add(block(channels=dec_channels[s], num_heads=dec_num_head[s], patch_size=dec_patch_size[s], drop_path=dp[i],
+                                  order_index=i % len(self.order), cpe_indice_key=f"stage{s}"), name=f"block{i}")
+                self.dec.add(module=dec, name=f"dec{s}")
+
+    def forward(self, data_dict):
+        """data_dict: "feat" [N, C], "grid_coord" [N, 3] (or "coord" + "grid_size"), "coord" [N, 3], "offset" or "batch" -> the
+        Point of the finest stage with its new "feat" [N, dec_channels[0]] (:445-460)."""
+        if self.training:
+            raise NotImplementedError("PointTransformerV3: inference only (call .eval()); the backward passes are not built")
+        point = Point(data_dict)
+        point.serialization(order=self.order, shuffle_orders=self.shuffle_orders)
+        point.sparsify()
+        point = self.embedding(point)
+        point = self.enc(point)
+        if not self.cls_mode:
+            point = self.dec(point)
+        return point

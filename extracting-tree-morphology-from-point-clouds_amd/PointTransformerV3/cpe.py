@@ -19,35 +19,38 @@ import torch.nn as nn
 from .. import _hip
 
 
-def subm_neighbors(batch, grid_coord):
-    """batch [N] int64 cloud ids (or None: one cloud), grid_coord [N, 3] integer voxel coordinates (0 .. 65533) -> nbr [N, 27]
-    int32: row i, column (dx + 1) * 9 + (dy + 1) * 3 + (dz + 1) = index of the voxel of the same cloud at grid_coord[i] +
-    (dx, dy, dz), or -1."""
+def subm_neighbors(batch, grid_coord, kernel_size=3):
+    """batch [N] int64 cloud ids (or None: one cloud), grid_coord [N, 3] integer voxel coordinates (0 .. 65533) -> nbr
+    [N, kernel_size^3] int32: row i, column ((dx + r) * k + (dy + r)) * k + (dz + r) (r = k // 2) = index of the voxel of the same
+    cloud at grid_coord[i] + (dx, dy, dz), or -1."""
     from .. import ops
     _hip.require_device(grid_coord)
     lib = _hip.lib()
     grid = grid_coord.to(torch.int32).contiguous()
-    N = grid.shape[0]
+    N, noff = grid.shape[0], int(kernel_size) ** 3
     dev = grid.device
     b = None if batch is None else batch.to(device=dev, dtype=torch.int64).contiguous()
-    nbr = torch.empty(N, 27, dtype=torch.int32, device=dev)
+    nbr = torch.empty(N, noff, dtype=torch.int32, device=dev)
     ws = torch.empty(lib.pn2_ptv3_subm_workspace_bytes(N), dtype=torch.uint8, device=dev)
-    _hip.call("ptv3_subm_neighbors", lib.pn2_ptv3_subm_neighbors_i32, _hip.ptr(b), grid.data_ptr(), N, nbr.data_ptr(), ws.data_ptr(),
-              ws.numel(), ops.status_word(dev).data_ptr(), _hip.stream_ptr(), nbytes=N * (20 + 27 * 4 + 27 * 12))
+    _hip.call("ptv3_subm_neighbors", lib.pn2_ptv3_subm_neighbors_i32, _hip.ptr(b), grid.data_ptr(), N, int(kernel_size), nbr.data_ptr(),
+              ws.data_ptr(), ws.numel(), ops.status_word(dev).data_ptr(), _hip.stream_ptr(), nbytes=N * (20 + noff * 16))
     return nbr
 
 
 class SubMConv3d(nn.Module):
-    """spconv.SubMConv3d(in_channels, out_channels, kernel_size=3, bias=True) on a neighbour table (see the module docstring)."""
+    """spconv.SubMConv3d(in_channels, out_channels, kernel_size, bias=...) on a neighbour table (see the module docstring).
+    kernel_size 3 (the CPE) or 5 (the stem of Embedding, blocks.py:783-791; `padding` is meaningless for a submanifold conv and
+    ignored, as spconv does).  An input width that is not a multiple of 16 (the stem's 4-6 raw features) is zero-padded."""
 
-    def __init__(self, in_channels, out_channels, kernel_size=3, bias=True, indice_key=None):
+    def __init__(self, in_channels, out_channels, kernel_size=3, padding=None, bias=True, indice_key=None):
         super().__init__()
-        if kernel_size != 3:
-            raise NotImplementedError("SubMConv3d: the CPE uses kernel_size = 3 (blocks.py:565)")
-        if in_channels % 16 or out_channels % 32:
-            raise NotImplementedError("SubMConv3d: C_in a multiple of 16, C_out of 32 (every stage of the repository's model is)")
-        self.in_channels, self.out_channels, self.indice_key = in_channels, out_channels, indice_key
-        self.weight = nn.Parameter(torch.empty(out_channels, 3, 3, 3, in_channels))
+        if kernel_size not in (3, 5):
+            raise NotImplementedError("SubMConv3d: kernel_size 3 (CPE, blocks.py:565) or 5 (stem, :787)")
+        if out_channels % 32:
+            raise NotImplementedError("SubMConv3d: C_out a multiple of 32 (every stage of the repository's model is)")
+        self.in_channels, self.out_channels, self.kernel_size, self.indice_key = in_channels, out_channels, kernel_size, indice_key
+        k = kernel_size
+        self.weight = nn.Parameter(torch.empty(out_channels, k, k, k, in_channels))
         self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
         self.reset_parameters()
         self._packed = None
@@ -55,15 +58,23 @@ class SubMConv3d(nn.Module):
     def reset_parameters(self):
         nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
         if self.bias is not None:
-            bound = 1.0 / math.sqrt(27 * self.in_channels)
+            bound = 1.0 / math.sqrt(self.kernel_size ** 3 * self.in_channels)
             nn.init.uniform_(self.bias, -bound, bound)
 
+    @property
+    def _cin_padded(self):
+        return (self.in_channels + 15) // 16 * 16
+
     def _offset_major(self):
-        """weight [C_out, kx, ky, kz, C_in] -> [27][C_in][C_out] (the kernel's slab per offset), cached per parameter version."""
+        """weight [C_out, kx, ky, kz, C_in] -> [k^3][C_in padded][C_out] (the kernel's slab per offset), cached per parameter
+        version."""
         key = (self.weight.data_ptr(), self.weight._version, self.weight.device)
         if self._packed is None or self._packed[0] != key:
-            w = self.weight.detach().float().permute(1, 2, 3, 4, 0).reshape(27, self.in_channels, self.out_channels).contiguous()
-            self._packed = (key, w)
+            noff = self.kernel_size ** 3
+            w = self.weight.detach().float().permute(1, 2, 3, 4, 0).reshape(noff, self.in_channels, self.out_channels)
+            if self._cin_padded != self.in_channels:
+                w = torch.nn.functional.pad(w, (0, 0, 0, self._cin_padded - self.in_channels))
+            self._packed = (key, w.contiguous())
         return self._packed[1]
 
     def forward(self, feat, nbr):
@@ -71,13 +82,18 @@ class SubMConv3d(nn.Module):
         if torch.is_grad_enabled() and feat.requires_grad:
             raise NotImplementedError("SubMConv3d: the backward pass is not built (inference only)")
         feat = _hip.f32(feat)
+        cin = self._cin_padded
+        if cin != self.in_channels:
+            feat = torch.nn.functional.pad(feat, (0, cin - self.in_channels))
         if feat.stride(1) != 1 or feat.stride(0) % 4:
             feat = feat.contiguous()
         N = feat.shape[0]
+        if nbr.shape != (N, self.kernel_size ** 3):
+            raise RuntimeError(f"SubMConv3d: neighbour table {tuple(nbr.shape)} does not fit {N} voxels, kernel_size {self.kernel_size}")
         out = torch.empty(N, self.out_channels, dtype=torch.float32, device=feat.device)
         w = self._offset_major()
         b = None if self.bias is None else self.bias.detach().float().contiguous()
-        _hip.call("ptv3_subm_conv", _hip.lib().pn2_ptv3_subm_conv_f32, feat.data_ptr(), feat.stride(0), nbr.data_ptr(), w.data_ptr(),
-                  _hip.ptr(b), N, self.in_channels, self.out_channels, out.data_ptr(), out.stride(0), _hip.stream_ptr(),
-                  nbytes=4 * N * (27 + self.in_channels + self.out_channels), flops=2 * 27 * N * self.in_channels * self.out_channels)
+        _hip.call("ptv3_subm_conv", _hip.lib().pn2_ptv3_subm_conv_f32, feat.data_ptr(), feat.stride(0), nbr.data_ptr(), self.kernel_size,
+                  w.data_ptr(), _hip.ptr(b), N, cin, self.out_channels, out.data_ptr(), out.stride(0), _hip.stream_ptr(),
+                  nbytes=4 * N * (nbr.shape[1] + cin + self.out_channels), flops=2 * nbr.shape[1] * N * cin * self.out_channels)
         return out

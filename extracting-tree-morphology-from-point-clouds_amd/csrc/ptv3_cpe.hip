@@ -67,11 +67,12 @@ __global__ __launch_bounds__(256) void voxel_insert_kernel(const long long* __re
 
 __global__ __launch_bounds__(256) void voxel_neighbors_kernel(const long long* __restrict__ batch, const int* __restrict__ grid, int N,
                                                               const u64* __restrict__ keys, const int* __restrict__ vals,
-                                                              unsigned mask, int32_t* __restrict__ nbr) {
+                                                              unsigned mask, int32_t* __restrict__ nbr, int ks) {
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= 27ll * N) return;
-    const int i = (int)(e / 27), d = (int)(e - 27ll * i);
-    const int dx = d / 9 - 1, dy = (d / 3) % 3 - 1, dz = d % 3 - 1;
+    const int noff = ks * ks * ks, rad = ks / 2;
+    if (e >= (long long)noff * N) return;
+    const int i = (int)(e / noff), d = (int)(e - (long long)noff * i);
+    const int dx = d / (ks * ks) - rad, dy = (d / ks) % ks - rad, dz = d % ks - rad;
     const int x = grid[3 * i], y = grid[3 * i + 1], z = grid[3 * i + 2];
     const long long b = batch ? batch[i] : 0;
     int found = -1;
@@ -100,7 +101,7 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 template <int CT>
 __global__ __launch_bounds__(256) void subm_conv_kernel(const float* __restrict__ feat, long long ldf, const int32_t* __restrict__ nbr,
                                                         const float* __restrict__ weight, const float* __restrict__ bias, int N,
-                                                        int Cin, int Cout, float* __restrict__ out, long long ldo) {
+                                                        int Cin, int Cout, float* __restrict__ out, long long ldo, int noff) {
     constexpr int NJ = CT / 32, BLD = CT + 4;
     __shared__ __attribute__((aligned(16))) float As[2][CBK * CLD];
     __shared__ __attribute__((aligned(16))) float Bs[2][CBK * BLD];
@@ -122,13 +123,13 @@ __global__ __launch_bounds__(256) void subm_conv_kernel(const float* __restrict_
     float vb[BPT];
     int buf = 0;
     bool first = true;
-    for (int d = 0; d < 27; ++d) {
+    for (int d = 0; d < noff; ++d) {
         // the two neighbours this thread gathers for offset d; does anybody in the tile have one?
         int j[2];
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int row = m0 + ra + 64 * p;
-            j[p] = row < N ? nbr[27ll * row + d] : -1;
+            j[p] = row < N ? nbr[(long long)noff * row + d] : -1;
         }
         if (!__syncthreads_or(j[0] >= 0 || j[1] >= 0)) continue;   // uniform: nobody in the tile needs this offset's slab
         const float* wd = weight + (long long)d * Cin * Cout;
@@ -334,9 +335,11 @@ extern "C" size_t pn2_ptv3_subm_workspace_bytes(int N) {
     return table_slots(N) * (sizeof(u64) + sizeof(int));
 }
 
-extern "C" int pn2_ptv3_subm_neighbors_i32(const int64_t* batch, const int32_t* grid_coord, int N, int32_t* nbr, void* workspace,
-                                           size_t workspace_bytes, int32_t* status, void* stream) {
-    if (!grid_coord || !nbr || N <= 0 || N > (1 << 30) / 27) return PN2_E_BADARG;
+extern "C" int pn2_ptv3_subm_neighbors_i32(const int64_t* batch, const int32_t* grid_coord, int N, int kernel_size, int32_t* nbr,
+                                           void* workspace, size_t workspace_bytes, int32_t* status, void* stream) {
+    if (!grid_coord || !nbr || N <= 0 || (kernel_size != 3 && kernel_size != 5)) return PN2_E_BADARG;
+    const int noff = kernel_size * kernel_size * kernel_size;
+    if (N > (1 << 30) / noff) return PN2_E_BADARG;
     if (!workspace || workspace_bytes < pn2_ptv3_subm_workspace_bytes(N)) return PN2_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     const size_t T = table_slots(N);
@@ -346,22 +349,24 @@ extern "C" int pn2_ptv3_subm_neighbors_i32(const int64_t* batch, const int32_t* 
     PN2_HIP_CHECK(hipMemsetAsync(vals, 0x7F, T * sizeof(int), s));   // (atomicMin target of duplicate voxels)
     PN2_LAUNCH("ptv3_voxel_insert", 28.0 * N, 0, voxel_insert_kernel, dim3(pn2::ceil_div(N, 256)), dim3(256), s,
                (const long long*)batch, grid_coord, N, keys, vals, (unsigned)(T - 1), status);
-    PN2_LAUNCH("ptv3_voxel_neighbors", 27.0 * 16.0 * N, 0, voxel_neighbors_kernel, dim3(pn2::ceil_div(27ll * N, 256)), dim3(256), s,
-               (const long long*)batch, grid_coord, N, (const u64*)keys, (const int*)vals, (unsigned)(T - 1), nbr);
+    PN2_LAUNCH("ptv3_voxel_neighbors", 16.0 * noff * N, 0, voxel_neighbors_kernel, dim3(pn2::ceil_div((long long)noff * N, 256)),
+               dim3(256), s, (const long long*)batch, grid_coord, N, (const u64*)keys, (const int*)vals, (unsigned)(T - 1), nbr,
+               kernel_size);
     PN2_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int pn2_ptv3_subm_conv_f32(const float* feat, int64_t ldf, const int32_t* nbr, const float* weight, const float* bias, int N,
-                                      int Cin, int Cout, float* out, int64_t ldo, void* stream) {
+extern "C" int pn2_ptv3_subm_conv_f32(const float* feat, int64_t ldf, const int32_t* nbr, int kernel_size, const float* weight,
+                                      const float* bias, int N, int Cin, int Cout, float* out, int64_t ldo, void* stream) {
     if (!feat || !nbr || !weight || !out || N <= 0 || Cin <= 0 || Cout <= 0 || Cin % CBK || Cout % 32 || ldf % 4 || ldf < Cin ||
-        ldo < Cout || ((uintptr_t)feat & 15) || ((uintptr_t)weight & 15))
+        ldo < Cout || ((uintptr_t)feat & 15) || ((uintptr_t)weight & 15) || (kernel_size != 3 && kernel_size != 5))
         return PN2_E_BADARG;
+    const int noff = kernel_size * kernel_size * kernel_size;
     hipStream_t s = (hipStream_t)stream;
     // rows compacted per offset from 128 input channels on (measured at 3.7 present neighbours, 1 M voxels: C = 128 7.0 -> 5.0 ms;
     // C = 64 2.06 -> 2.00; C = 32 0.68 -> 0.92: an item's per-K-tile round trips are not amortised by narrow rows);
     // PN2_CPE_DENSE_TILES=1 / PN2_CPE_COMPACT=1 force either kernel (A/B aid)
-    if ((Cin >= 128 || getenv("PN2_CPE_COMPACT")) && !getenv("PN2_CPE_DENSE_TILES")) {
+    if (noff == 27 && (Cin >= 128 || getenv("PN2_CPE_COMPACT")) && !getenv("PN2_CPE_DENSE_TILES")) {
         const int ctc = Cout % 64 == 0 ? 64 : 32;
         const dim3 gridc(pn2::ceil_div(N, CT_ROWS), Cout / ctc);
         const double fl = 2.0 * 27.0 * N * (double)Cin * Cout, by = 4.0 * N * (27.0 + Cin + Cout) + 4.0 * 27.0 * Cin * Cout;
@@ -376,17 +381,17 @@ extern "C" int pn2_ptv3_subm_conv_f32(const float* feat, int64_t ldf, const int3
     }
     const int ct = Cout % 128 == 0 ? 128 : (Cout % 64 == 0 ? 64 : 32);
     const dim3 grid(pn2::ceil_div(N, CT_ROWS), Cout / ct);
-    const double flops = 2.0 * 27.0 * N * (double)Cin * Cout;   // upper bound: the dense stencil (skipped slabs do no work)
-    const double bytes = 4.0 * N * (27.0 + Cin + Cout) + 4.0 * 27.0 * Cin * Cout;
+    const double flops = 2.0 * noff * N * (double)Cin * Cout;   // upper bound: the dense stencil (skipped slabs do no work)
+    const double bytes = 4.0 * N * ((double)noff + Cin + Cout) + 4.0 * noff * Cin * Cout;
     if (ct == 128)
         PN2_LAUNCH("ptv3_subm_conv", bytes, flops, (subm_conv_kernel<128>), grid, dim3(256), s, feat, (long long)ldf, nbr, weight, bias, N,
-                   Cin, Cout, out, (long long)ldo);
+                   Cin, Cout, out, (long long)ldo, noff);
     else if (ct == 64)
         PN2_LAUNCH("ptv3_subm_conv", bytes, flops, (subm_conv_kernel<64>), grid, dim3(256), s, feat, (long long)ldf, nbr, weight, bias, N,
-                   Cin, Cout, out, (long long)ldo);
+                   Cin, Cout, out, (long long)ldo, noff);
     else
         PN2_LAUNCH("ptv3_subm_conv", bytes, flops, (subm_conv_kernel<32>), grid, dim3(256), s, feat, (long long)ldf, nbr, weight, bias, N,
-                   Cin, Cout, out, (long long)ldo);
+                   Cin, Cout, out, (long long)ldo, noff);
     PN2_LAUNCH_CHECK();
     return 0;
 }

@@ -580,12 +580,15 @@ int pn2_serialize_decode_i64(const int64_t *codes, long long N, int depth, int o
  *   workspace: pn2_ptv3_subm_workspace_bytes(N) (the hash table; contents irrelevant on entry).
  * pn2_ptv3_subm_conv_f32        feat [N][C_in] (row stride ldf, a multiple of 4), weight [27][C_in][C_out] (offset-major: the
  *   mirror permutes spconv's [C_out][3][3][3][C_in] parameter), bias [C_out] or NULL -> out [N][C_out] (row stride ldo).
- *   C_in a multiple of 16, C_out of 32.  fp32 (v_mfma_f32_32x32x2_f32).  Forward only. */
+ *   C_in a multiple of 16, C_out of 32.  fp32 (v_mfma_f32_32x32x2_f32).  Forward only.
+ * kernel_size 3 (the CPE: 27 offsets) or 5 (the stem of Embedding, blocks.py:783-791: 125 offsets, index
+ *   (dx + 2) * 25 + (dy + 2) * 5 + (dz + 2); nbr [N][125], weight [125][C_in][C_out]); a C_in that is not a multiple of 16 (the stem's
+ *   input features) is zero-padded by the caller. */
 size_t pn2_ptv3_subm_workspace_bytes(int N);
-int pn2_ptv3_subm_neighbors_i32(const int64_t *batch, const int32_t *grid_coord, int N, int32_t *nbr, void *workspace,
-                                size_t workspace_bytes, int32_t *status, void *stream);
-int pn2_ptv3_subm_conv_f32(const float *feat, int64_t ldf, const int32_t *nbr, const float *weight, const float *bias, int N,
-                           int Cin, int Cout, float *out, int64_t ldo, void *stream);
+int pn2_ptv3_subm_neighbors_i32(const int64_t *batch, const int32_t *grid_coord, int N, int kernel_size, int32_t *nbr,
+                                void *workspace, size_t workspace_bytes, int32_t *status, void *stream);
+int pn2_ptv3_subm_conv_f32(const float *feat, int64_t ldf, const int32_t *nbr, int kernel_size, const float *weight,
+                           const float *bias, int N, int Cin, int Cout, float *out, int64_t ldo, void *stream);
 
 #ifdef __cplusplus
 }

@@ -8,35 +8,37 @@ import numpy as np
 import torch
 
 
-def subm_neighbors(batch, grid_coord):
-    """-> int32 [N, 27]: column (dx + 1) * 9 + (dy + 1) * 3 + (dz + 1) = index of the active voxel of the same cloud at
-    grid_coord[i] + (dx, dy, dz), or -1.  Duplicate voxels are represented by their lowest index."""
+def subm_neighbors(batch, grid_coord, kernel_size=3):
+    """-> int32 [N, k^3]: column ((dx + r) * k + (dy + r)) * k + (dz + r), r = k // 2, = index of the active voxel of the same cloud
+    at grid_coord[i] + (dx, dy, dz), or -1.  Duplicate voxels are represented by their lowest index."""
     grid = np.asarray(grid_coord, dtype=np.int64)
-    N = len(grid)
+    N, k = len(grid), int(kernel_size)
+    r = k // 2
     b = np.zeros(N, np.int64) if batch is None else np.asarray(batch, dtype=np.int64)
     table = {}
     for i in range(N - 1, -1, -1):                      # lowest index wins
         table[(int(b[i]), int(grid[i, 0]), int(grid[i, 1]), int(grid[i, 2]))] = i
-    nbr = np.full((N, 27), -1, np.int32)
+    nbr = np.full((N, k ** 3), -1, np.int32)
     for i in range(N):
         bi, x, y, z = int(b[i]), int(grid[i, 0]), int(grid[i, 1]), int(grid[i, 2])
-        for dx in (-1, 0, 1):
-            for dy in (-1, 0, 1):
-                for dz in (-1, 0, 1):
+        for dx in range(-r, r + 1):
+            for dy in range(-r, r + 1):
+                for dz in range(-r, r + 1):
                     j = table.get((bi, x + dx, y + dy, z + dz))
                     if j is not None:
-                        nbr[i, (dx + 1) * 9 + (dy + 1) * 3 + (dz + 1)] = j
+                        nbr[i, ((dx + r) * k + (dy + r)) * k + (dz + r)] = j
     return nbr
 
 
 def subm_conv(feat, nbr, weight, bias):
-    """feat [N, C_in], nbr [N, 27], weight [C_out, 3, 3, 3, C_in] (spconv 2.x), bias [C_out] or None -> [N, C_out] float64:
+    """feat [N, C_in], nbr [N, k^3], weight [C_out, k, k, k, C_in] (spconv 2.x), bias [C_out] or None -> [N, C_out] float64:
     out[i] = bias + sum_d W[:, d, :] feat[nbr[i, d]]."""
     feat = torch.as_tensor(feat, dtype=torch.float64)
-    w = torch.as_tensor(weight, dtype=torch.float64).reshape(weight.shape[0], 27, weight.shape[-1])   # [C_out, 27, C_in]
+    noff = nbr.shape[1]
+    w = torch.as_tensor(weight, dtype=torch.float64).reshape(weight.shape[0], noff, weight.shape[-1])   # [C_out, k^3, C_in]
     nbr = torch.as_tensor(np.asarray(nbr), dtype=torch.long)
     out = torch.zeros(feat.shape[0], w.shape[0], dtype=torch.float64)
-    for d in range(27):
+    for d in range(noff):
         j = nbr[:, d]
         ok = j >= 0
         out[ok] += feat[j[ok]] @ w[:, d, :].t()
@@ -56,6 +58,7 @@ def dense_reference(batch, grid_coord, feat, weight, bias):
     X, Y, Z = (int(grid[:, a].max()) + 1 for a in range(3))
     dense = torch.zeros(B, feat.shape[1], X, Y, Z, dtype=torch.float64)
     dense[b, :, grid[:, 0], grid[:, 1], grid[:, 2]] = feat
-    w = torch.as_tensor(weight, dtype=torch.float64).permute(0, 4, 1, 2, 3).contiguous()      # [C_out, C_in, 3, 3, 3]
-    out = torch.nn.functional.conv3d(dense, w, None if bias is None else torch.as_tensor(bias, dtype=torch.float64), padding=1)
+    w = torch.as_tensor(weight, dtype=torch.float64).permute(0, 4, 1, 2, 3).contiguous()      # [C_out, C_in, k, k, k]
+    out = torch.nn.functional.conv3d(dense, w, None if bias is None else torch.as_tensor(bias, dtype=torch.float64),
+                                     padding=weight.shape[1] // 2)
     return out[b, :, grid[:, 0], grid[:, 1], grid[:, 2]]

@@ -41,6 +41,13 @@ def test_oracle_is_the_dense_conv3d_at_the_active_voxels():
     got = P.subm_conv(feat, nbr, w, bias)
     want = P.dense_reference(batch, grid, feat, w, bias)
     assert float((got - want).abs().max()) <= 1e-12 * float(want.abs().max())
+    # the stem's 5 x 5 x 5 kernel on a few raw features (Embedding, blocks.py:783-791)
+    w5 = rng.standard_normal((32, 5, 5, 5, 6)) * 0.1
+    f5 = rng.standard_normal((len(grid), 6))
+    nbr5 = P.subm_neighbors(batch, grid, 5)
+    assert nbr5.shape[1] == 125 and (nbr5[:, 62] == np.arange(len(grid))).all()
+    got5, want5 = P.subm_conv(f5, nbr5, w5, None), P.dense_reference(batch, grid, f5, w5, None)
+    assert float((got5 - want5).abs().max()) <= 1e-12 * float(want5.abs().max())
     # a neighbour of another cloud at the same coordinates is not a neighbour
     nb2 = P.subm_neighbors(np.array([0, 1]), np.array([[3, 3, 3], [3, 3, 4]]))
     assert (nb2[0] >= 0).sum() == 1 and (nb2[1] >= 0).sum() == 1
@@ -98,3 +105,24 @@ def test_subm_neighbors_rejects_out_of_range_voxels_loudly():
     assert (nbr[2] == -1).all() and int(nbr[0, 14]) == 1 and int(nbr[1, 12]) == 0
     with pytest.raises(RuntimeError):
         ops.check_status()
+
+
+@pytest.mark.gpu
+def test_stem_conv_5x5x5_on_raw_features():
+    """Embedding's stem (blocks.py:783-791): SubMConv3d(in_channels = 6, 32, kernel_size = 5, bias = False) -- 125 offsets, the
+    input width zero-padded to 16."""
+    helpers.load_pkg()
+    from oracle import ptv3_cpe_port as P
+    from pn2_amd.PointTransformerV3 import cpe
+    batch, grid = _voxels(2500, 2, 30, seed=77)
+    N = len(grid)
+    feat = np.random.default_rng(6).standard_normal((N, 6)).astype(np.float32)
+    want_nbr = P.subm_neighbors(batch, grid, 5)
+    nbr = cpe.subm_neighbors(torch.from_numpy(batch).cuda(), torch.from_numpy(grid).cuda(), kernel_size=5)
+    assert np.array_equal(nbr.cpu().numpy(), want_nbr)
+    torch.manual_seed(4)
+    conv = cpe.SubMConv3d(6, 32, kernel_size=5, padding=1, bias=False).cuda()
+    with torch.no_grad():
+        out = conv(torch.from_numpy(feat).cuda(), nbr)
+    want = P.subm_conv(feat, want_nbr, conv.weight.detach().cpu().numpy(), None)
+    assert float((out.cpu().double() - want).abs().max()) <= 2e-6 * float(want.abs().max())

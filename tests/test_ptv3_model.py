@@ -1,0 +1,94 @@
+"""PointTransformerV3 backbone (BASELINE configs[3]) assembled from this library's kernels -- serialization
+codes, serialized patch attention, submanifold convolutions of the stem and of every Block's positional encoding -- and plain
+torch layers, with the reference's module tree (Modules/PointTransformerV3/PointTransformerV3.py:261-460).  PARITY UNPINNED
+against the reference (not importable here); the yardstick is the float64 restatement oracle/ptv3_model_port.py."""
+import numpy as np
+import pytest
+import torch
+
+import helpers
+
+
+def _cfg(depth=1):
+    return dict(in_channels=4, order=("z", "z-trans", "hilbert", "hilbert-trans"), stride=(2, 2, 2, 2), enc_depths=(depth,) * 5,
+                enc_channels=(32, 64, 128, 256, 512), enc_num_head=(2, 4, 8, 16, 32), enc_patch_size=(64,) * 5,
+                dec_depths=(depth,) * 4, dec_channels=(64, 64, 128, 256), dec_num_head=(4, 4, 8, 16), dec_patch_size=(64,) * 4,
+                shuffle_orders=False)
+
+
+def test_state_dict_has_the_reference_layout():
+    """The names and shapes a checkpoint of the reference's `backbone` holds (spconv 2.x weight layout for the convolutions)."""
+    helpers.load_pkg()
+    from pn2_amd.PointTransformerV3.PointTransformerV3 import PointTransformerV3
+    sd = PointTransformerV3(in_channels=4).state_dict()
+    want = {"embedding.stem.conv.weight": (32, 5, 5, 5, 4), "embedding.stem.norm.running_var": (32,),
+            "enc.enc0.block1.cpe.0.weight": (32, 3, 3, 3, 32), "enc.enc0.block1.cpe.0.bias": (32,),
+            "enc.enc0.block0.cpe.1.weight": (32, 32), "enc.enc0.block0.cpe.2.weight": (32,), "enc.enc0.block0.norm1.0.bias": (32,),
+            "enc.enc1.down.proj.weight": (64, 32), "enc.enc1.down.norm.0.running_mean": (64,),
+            "enc.enc3.block5.attn.qkv.weight": (768, 256), "enc.enc3.block5.attn.proj.bias": (256,),
+            "enc.enc4.block1.mlp.0.fc1.weight": (2048, 512), "enc.enc4.block1.mlp.0.fc2.bias": (512,),
+            "dec.dec3.up.proj.0.weight": (256, 512), "dec.dec3.up.proj_skip.0.weight": (256, 256),
+            "dec.dec0.up.proj_skip.1.num_batches_tracked": (), "dec.dec0.block1.norm2.0.weight": (64,)}
+    for k, shape in want.items():
+        assert k in sd and tuple(sd[k].shape) == shape, k
+    assert "embedding.stem.conv.bias" not in sd
+    assert sum(1 for k in sd if k.endswith("cpe.0.weight")) == 14 + 8
+
+
+@pytest.mark.gpu
+def test_backbone_forward_matches_float64_restatement():
+    helpers.load_pkg()
+    from oracle import ptv3_model_port as P
+    from pn2_amd.PointTransformerV3.PointTransformerV3 import PointTransformerV3
+    from pn2_amd.synthetic import gaussian_branch_tree
+    cfg = _cfg()
+    torch.manual_seed(0)
+    model = PointTransformerV3(**cfg).cuda().eval()
+    for m in model.modules():
+        # the reference constructs its poolings with the default shuffle_orders=True (PointTransformerV3.py:350-358), i.e. WHICH
+        # serialization a Block of the deeper stages uses is drawn at random even at inference; switched off to compare
+        if hasattr(m, "shuffle_orders"):
+            m.shuffle_orders = False
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():   # running statistics and norm affine parameters away from their initial 0 / 1
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.2)
+                m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+            if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.LayerNorm)):
+                m.weight.copy_(torch.rand(m.weight.shape, generator=g) + 0.5)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+    clouds = []
+    for b in range(2):
+        xyz = gaussian_branch_tree(6000, seed=10 + b)[0]
+        grid = np.unique(np.floor((xyz - xyz.min(0)) / 0.05).astype(np.int64), axis=0)
+        clouds.append(np.concatenate([np.full((len(grid), 1), b), grid], 1))
+    vox = np.concatenate(clouds)
+    batch, grid = vox[:, 0].copy(), vox[:, 1:].copy()
+    N = len(grid)
+    assert N > 2500
+    rng = np.random.default_rng(2)
+    feat = rng.standard_normal((N, 4)).astype(np.float32)
+    coord = (grid * 0.05).astype(np.float32)
+    with torch.no_grad():
+        point = model({"feat": torch.from_numpy(feat).cuda(), "coord": torch.from_numpy(coord).cuda(),
+                       "grid_coord": torch.from_numpy(grid).cuda().int(), "batch": torch.from_numpy(batch).cuda()})
+    out = point.feat
+    assert tuple(out.shape) == (N, 64)
+    want = P.backbone_forward(model.state_dict(), cfg, feat, coord, grid, batch)
+    err = float((out.cpu().double() - want).abs().max()) / float(want.abs().max())
+    assert err <= 2e-4, err
+
+
+@pytest.mark.gpu
+def test_training_mode_and_unbuilt_options_raise():
+    helpers.load_pkg()
+    from pn2_amd.PointTransformerV3.PointTransformerV3 import PointTransformerV3
+    with pytest.raises(NotImplementedError):
+        PointTransformerV3(in_channels=4, pdnorm_bn=True)
+    with pytest.raises(NotImplementedError):
+        PointTransformerV3(in_channels=4, enable_flash=True)
+    model = PointTransformerV3(**_cfg()).cuda().train()
+    with pytest.raises(NotImplementedError):
+        model({"feat": torch.zeros(10, 4).cuda(), "coord": torch.zeros(10, 3).cuda(), "grid_coord": torch.zeros(10, 3).int().cuda(),
+               "batch": torch.zeros(10, dtype=torch.long).cuda()})
