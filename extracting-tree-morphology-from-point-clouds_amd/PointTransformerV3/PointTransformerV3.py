@@ -80,3 +80,105 @@ class PointTransformerV3(PointModule):
         if not self.cls_mode:
             point = self.dec(point)
         return point
+
+
+class MLP_Head(nn.Sequential):
+    """blocks.py:42-62: Linear -> norm -> ReLU (num_layers - 1 times) -> Linear."""
+
+    def __init__(self, in_channels, out_channels, norm_fn=None, num_layers=2):
+        modules = []
+        for _ in range(num_layers - 1):
+            modules.append(nn.Linear(in_channels, in_channels))
+            if norm_fn:
+                modules.append(norm_fn(in_channels))
+            modules.append(nn.ReLU())
+        modules.append(nn.Linear(in_channels, out_channels))
+        super().__init__(*modules)
+
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.xavier_uniform_(m.weight)
+                nn.init.constant_(m.bias, 0)
+        nn.init.normal_(self[-1].weight, 0, 0.01)
+        nn.init.constant_(self[-1].bias, 0)
+
+
+class PointTransformerWithHeads(nn.Module):
+    """PointTransformerV3.py:19-258 at inference: the backbone on the voxels of `coords` at `voxel_size` (several points may share a
+    voxel: a duplicate voxel is represented by its lowest-index point in the neighbour tables), the semantic and the offset head on
+    its 64 output features, `forward(batch, return_loss)` and the prediction-averaging `forward_hierarchical_streaming(batch,
+    return_loss=False)`.  `return_loss=True` evaluates the reference's loss on the outputs (validation); training mode raises."""
+
+    def __init__(self, dim_feat=4, use_feats=False, voxel_size=0.02, loss_multiplier_semantic=1, loss_multiplier_offset=1,
+                 enable_flash=False, optional_autocast=True, **kwargs):
+        super().__init__()
+        self.voxel_size, self.use_feats, self.optional_autocast = voxel_size, use_feats, optional_autocast
+        self.loss_multiplier_semantic, self.loss_multiplier_offset = loss_multiplier_semantic, loss_multiplier_offset
+        self.backbone = PointTransformerV3(in_channels=dim_feat, enable_flash=enable_flash)
+        norm_fn = partial(nn.BatchNorm1d, eps=1e-4, momentum=0.1)
+        self.semantic_linear = MLP_Head(64, 2, norm_fn=norm_fn, num_layers=2)
+        self.offset_linear = MLP_Head(64, 3, norm_fn=norm_fn, num_layers=2)
+        self.init_weights()
+
+    def init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.BatchNorm1d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+            elif isinstance(m, MLP_Head):
+                m.init_weights()
+
+    def _point_dict(self, batch):
+        feats = batch["feats"]
+        if not self.use_feats:
+            feats = torch.ones_like(feats)
+        return {"coord": batch["coords"].to("cuda"), "feat": feats.to("cuda"), "grid_size": self.voxel_size,
+                "batch": batch["batch_ids"].to("cuda")}
+
+    def forward_backbone(self, point_dict, **kwargs):
+        return self.backbone(point_dict)
+
+    def forward_head(self, backbone_output, **kwargs):
+        feats = backbone_output["feat"]
+        return {"backbone_feats": feats, "semantic_prediction_logits": self.semantic_linear(feats),
+                "offset_predictions": self.offset_linear(feats)}
+
+    def forward(self, batch, return_loss, **kwargs):
+        output = self.forward_head(self.forward_backbone(self._point_dict(batch)))
+        if return_loss:
+            output = self.get_loss(model_output=output, **batch)
+        return output
+
+    def get_loss(self, model_output, semantic_labels, offset_labels, masks_off, **kwargs):
+        from ..Loss import point_wise_loss
+        sem, off = point_wise_loss(model_output["semantic_prediction_logits"].float(), model_output["offset_predictions"][masks_off].float(),
+                                   semantic_labels, offset_labels[masks_off])
+        loss_dict = {"semantic_loss": sem * self.loss_multiplier_semantic, "offset_loss": off * self.loss_multiplier_offset}
+        return sum(loss_dict.values()), loss_dict
+
+    @torch.no_grad()
+    def forward_hierarchical_streaming(self, batch, return_loss=False, scaler=None):
+        """:117-243 for return_loss=False: per-mini-batch predictions averaged over the tree (`avg[ids] += x`, the reference's
+        index_put: one contribution per id and mini-batch)."""
+        if return_loss:
+            raise NotImplementedError("PointTransformerWithHeads: the training pass of forward_hierarchical_streaming is not built")
+        n, dev = batch["cloud_length"], "cuda"
+        avg_off, avg_sem = torch.zeros((n, 3), device=dev), torch.zeros((n, 2), device=dev)
+        cnt_sem, cnt_off = torch.zeros((n, 1), device=dev), torch.zeros((n, 1), device=dev)
+        for mb in batch["mini_batches"]:
+            out = self.forward_head(self.forward_backbone(self._point_dict(mb)))
+            ids, mask_off = mb["point_ids"].to(dev), mb["masks_off"].to(dev)
+            sem, off = out["semantic_prediction_logits"], out["offset_predictions"]
+            if "masks_pad" in mb and sem.shape[0] == mb["masks_pad"].numel():
+                keep = mb["masks_pad"].reshape(-1).to(dev)
+                sem, off = sem[keep], off[keep]
+            off, ids_off = off[mask_off], ids[mask_off]
+            avg_sem[ids] += sem
+            avg_off[ids_off] += off
+            cnt_sem[ids] += 1
+            cnt_off[ids_off] += 1
+        ok_s, ok_o = cnt_sem.squeeze(1) > 0, cnt_off.squeeze(1) > 0
+        avg_sem[ok_s] /= cnt_sem[ok_s]
+        avg_off[ok_o] /= cnt_off[ok_o]
+        return {"semantic_prediction_logits": avg_sem, "offset_predictions": avg_off}

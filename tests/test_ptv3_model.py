@@ -92,3 +92,38 @@ def test_training_mode_and_unbuilt_options_raise():
     with pytest.raises(NotImplementedError):
         model({"feat": torch.zeros(10, 4).cuda(), "coord": torch.zeros(10, 3).cuda(), "grid_coord": torch.zeros(10, 3).int().cuda(),
                "batch": torch.zeros(10, dtype=torch.long).cuda()})
+
+
+@pytest.mark.gpu
+def test_model_with_heads_on_points_that_share_voxels():
+    """PointTransformerWithHeads (PointTransformerV3.py:19-115) at inference: points -> voxels at voxel_size (several points per
+    voxel), backbone, the two heads; the outputs are the heads applied to the backbone's rows, and the averaged streaming
+    predictions of one mini-batch equal the direct ones."""
+    helpers.load_pkg()
+    from pn2_amd.PointTransformerV3.PointTransformerV3 import PointTransformerWithHeads
+    from pn2_amd.synthetic import gaussian_branch_tree
+    torch.manual_seed(0)
+    model = PointTransformerWithHeads(dim_feat=4, voxel_size=0.05).cuda().eval()
+    for m in model.modules():
+        if hasattr(m, "shuffle_orders"):
+            m.shuffle_orders = False
+    xyz = gaussian_branch_tree(20000, seed=3)[0]
+    n = len(xyz)
+    batch = {"coords": torch.from_numpy(xyz), "feats": torch.randn(n, 4), "batch_ids": torch.zeros(n, dtype=torch.long)}
+    with torch.no_grad():
+        out = model(batch, return_loss=False)
+    assert tuple(out["semantic_prediction_logits"].shape) == (n, 2) and tuple(out["offset_predictions"].shape) == (n, 3)
+    assert tuple(out["backbone_feats"].shape) == (n, 64) and bool(torch.isfinite(out["offset_predictions"]).all())
+    grid = torch.div(torch.from_numpy(xyz) - torch.from_numpy(xyz).min(0)[0], 0.05, rounding_mode="trunc").int()
+    assert len(torch.unique(grid, dim=0)) < n                      # points do share voxels
+    with torch.no_grad():
+        want = model.offset_linear(out["backbone_feats"])
+    assert torch.equal(want, out["offset_predictions"])
+    tree = {"cloud_length": n, "mini_batches": [dict(batch, point_ids=torch.arange(n), masks_off=torch.ones(n, dtype=torch.bool))]}
+    avg = model.forward_hierarchical_streaming(tree, return_loss=False)
+    assert float((avg["offset_predictions"] - out["offset_predictions"]).abs().max()) <= 1e-5 * float(out["offset_predictions"].abs().max()) + 1e-7
+    sem = torch.zeros(n, dtype=torch.long).cuda()
+    with torch.no_grad():
+        loss, ld = model(dict(batch, semantic_labels=sem, offset_labels=torch.zeros(n, 3).cuda(), masks_off=torch.ones(n, dtype=torch.bool).cuda()),
+                         return_loss=True)
+    assert bool(torch.isfinite(loss)) and set(ld) == {"semantic_loss", "offset_loss"}
