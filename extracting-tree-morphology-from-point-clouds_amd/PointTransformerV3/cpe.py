@@ -18,6 +18,8 @@ import torch.nn as nn
 
 from .. import _hip
 
+CONV_PRECISION = "f32"          # "f32" (exact fp32 MFMA: the parity mode) or "bf16" (bfloat16 operands for the layers >= 64 wide)
+
 
 def subm_neighbors(batch, grid_coord, kernel_size=3):
     """batch [N] int64 cloud ids (or None: one cloud), grid_coord [N, 3] integer voxel coordinates (0 .. 65533) -> nbr
@@ -54,6 +56,7 @@ class SubMConv3d(nn.Module):
         self.bias = nn.Parameter(torch.empty(out_channels)) if bias else None
         self.reset_parameters()
         self._packed = None
+        self._packed16 = None
 
     def reset_parameters(self):
         nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
@@ -77,6 +80,14 @@ class SubMConv3d(nn.Module):
             self._packed = (key, w.contiguous())
         return self._packed[1]
 
+    def _offset_major_bf16(self):
+        """weight -> bfloat16 [27][C_out][C_in] (eight consecutive input channels of a column contiguous), cached per version."""
+        key = (self.weight.data_ptr(), self.weight._version, self.weight.device)
+        if self._packed16 is None or self._packed16[0] != key:
+            w = self.weight.detach().float().reshape(self.out_channels, 27, self.in_channels).permute(1, 0, 2)
+            self._packed16 = (key, w.to(torch.bfloat16).contiguous())
+        return self._packed16[1]
+
     def forward(self, feat, nbr):
         _hip.require_device(feat, nbr)
         if torch.is_grad_enabled() and feat.requires_grad:
@@ -92,8 +103,9 @@ class SubMConv3d(nn.Module):
             raise RuntimeError(f"SubMConv3d: neighbour table {tuple(nbr.shape)} does not fit {N} voxels, kernel_size {self.kernel_size}")
         out = torch.empty(N, self.out_channels, dtype=torch.float32, device=feat.device)
         w = self._offset_major()
+        w16 = self._offset_major_bf16() if (CONV_PRECISION == "bf16" and self.kernel_size == 3 and cin >= 64) else None
         b = None if self.bias is None else self.bias.detach().float().contiguous()
         _hip.call("ptv3_subm_conv", _hip.lib().pn2_ptv3_subm_conv_f32, feat.data_ptr(), feat.stride(0), nbr.data_ptr(), self.kernel_size,
-                  w.data_ptr(), _hip.ptr(b), N, cin, self.out_channels, out.data_ptr(), out.stride(0), _hip.stream_ptr(),
+                  w.data_ptr(), _hip.ptr(w16), _hip.ptr(b), N, cin, self.out_channels, out.data_ptr(), out.stride(0), _hip.stream_ptr(),
                   nbytes=4 * N * (nbr.shape[1] + cin + self.out_channels), flops=2 * nbr.shape[1] * N * cin * self.out_channels)
         return out

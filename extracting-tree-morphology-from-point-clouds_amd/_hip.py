@@ -115,7 +115,7 @@ SIGNATURES = {
     "pn2_serialize_decode_i64": (_int, [_vp, ctypes.c_longlong, _int, _int, _vp, _vp, _vp]),
     "pn2_ptv3_subm_workspace_bytes": (_sz, [_int]),
     "pn2_ptv3_subm_neighbors_i32": (_int, [_vp, _vp, _int, _int, _vp, _vp, _sz, _vp, _vp]),
-    "pn2_ptv3_subm_conv_f32": (_int, [_vp, _i64, _vp, _int, _vp, _vp, _int, _int, _int, _vp, _i64, _vp]),
+    "pn2_ptv3_subm_conv_f32": (_int, [_vp, _i64, _vp, _int, _vp, _vp, _vp, _int, _int, _int, _vp, _i64, _vp]),
     "pn2_ptv3_pad_unpad_i64": (_int, [_vp, _vp, _vp, _int, _int, _i64, _vp, _vp, _vp, _vp]),
     "pn2_ptv3_patch_attention_f32": (_int, [_vp, _i64, _vp, _i64, _int, _int, _int, _f32, _vp, _int, _vp]),
     "pn2_prof_enable": (None, [_int]),

@@ -228,7 +228,12 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 constexpr int ALD = 36;   // row pitch (floats) of a wavefront's [k][32 rows] staging buffer
 
-template <int CT>   // columns per workgroup: 32 or 64
+// BF16 (throughput mode, like the attention's): the gathered rows are rounded to bfloat16 on their way into the wavefront's LDS
+// image ([32 rows][16 k], 48-byte pitch: the matrix-core operand is one 16-byte read), the weights come as a bfloat16 copy
+// [27][C_out][C_in] (eight consecutive k of a column = one 16-byte load), v_mfma_f32_32x32x16_bf16, fp32 accumulation and output.
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+template <int CT, bool BF16>   // columns per workgroup: 32 or 64
 __global__ __launch_bounds__(256) void subm_conv_compact_kernel(const float* __restrict__ feat, long long ldf,
                                                                 const int32_t* __restrict__ nbr, const float* __restrict__ weight,
                                                                 const float* __restrict__ bias, int N, int Cin, int Cout,
@@ -256,6 +261,7 @@ __global__ __launch_bounds__(256) void subm_conv_compact_kernel(const float* __r
         const int clo = __popcll(mlo), count = clo + __popcll(mhi);
         const int nblk = (count + 31) >> 5;
         const float* wd = weight + (long long)d * Cin * Cout + n0;
+        const __bf16* wd16 = (const __bf16*)weight + ((long long)d * Cout + n0) * Cin;   // BF16: [27][C_out][C_in]
         for (int blk = 0; blk < nblk; ++blk, ++item) {
             if ((item & 3) != wave) continue;   // wave-uniform
             // this lane's compacted row (both half-wavefronts hold the same 32 rows)
@@ -275,21 +281,54 @@ __global__ __launch_bounds__(256) void subm_conv_compact_kernel(const float* __r
                 for (int r = 0; r < 16; ++r) acc[jn][r] = 0.0f;
             float4 va = jA >= 0 ? *(const float4*)(feat + (long long)jA * ldf + ka) : make_float4(0.f, 0.f, 0.f, 0.f);
             float4 vb = jB >= 0 ? *(const float4*)(feat + (long long)jB * ldf + ka) : make_float4(0.f, 0.f, 0.f, 0.f);
+            bf16x8 bw16[NJ];
+            float bw[CBK / 2][NJ];
+            if constexpr (BF16) {
+#pragma unroll
+                for (int jn = 0; jn < NJ; ++jn) bw16[jn] = *(const bf16x8*)(wd16 + (long long)(32 * jn + l31) * Cin + 8 * half);
+            } else {
+#pragma unroll
+                for (int s2 = 0; s2 < CBK / 2; ++s2)
+#pragma unroll
+                    for (int jn = 0; jn < NJ; ++jn) bw[s2][jn] = wd[(long long)(2 * s2 + half) * Cout + 32 * jn + l31];
+            }
             for (int kt = 0; kt < ktiles; ++kt) {
                 float* A = Aw[wave][kt & 1];
+                const int k0 = kt * CBK;
+                if constexpr (BF16) {
+                    char* A16 = (char*)A;
+                    *(bf16x4*)(A16 + (lane >> 2) * 48 + 2 * ka) = bf16x4{(__bf16)va.x, (__bf16)va.y, (__bf16)va.z, (__bf16)va.w};
+                    *(bf16x4*)(A16 + (16 + (lane >> 2)) * 48 + 2 * ka) = bf16x4{(__bf16)vb.x, (__bf16)vb.y, (__bf16)vb.z, (__bf16)vb.w};
+                    bf16x8 bnext[NJ];   // the NEXT tile's weight fragments and rows: every load a K-tile ahead of its use
+                    if (kt + 1 < ktiles) {
+#pragma unroll
+                        for (int jn = 0; jn < NJ; ++jn)
+                            bnext[jn] = *(const bf16x8*)(wd16 + (long long)(32 * jn + l31) * Cin + k0 + CBK + 8 * half);
+                        va = jA >= 0 ? *(const float4*)(feat + (long long)jA * ldf + k0 + CBK + ka) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        vb = jB >= 0 ? *(const float4*)(feat + (long long)jB * ldf + k0 + CBK + ka) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                    wave_lds_sync();
+                    const bf16x8 af = *(const bf16x8*)(A16 + l31 * 48 + 16 * half);
+#pragma unroll
+                    for (int jn = 0; jn < NJ; ++jn) acc[jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bw16[jn], acc[jn], 0, 0, 0);
+                    if (kt + 1 < ktiles) {
+#pragma unroll
+                        for (int jn = 0; jn < NJ; ++jn) bw16[jn] = bnext[jn];
+                    }
+                    continue;
+                }
                 {
                     float* dst = A + ka * ALD + (lane >> 2);
                     dst[0] = va.x, dst[ALD] = va.y, dst[2 * ALD] = va.z, dst[3 * ALD] = va.w;
                     dst[16] = vb.x, dst[ALD + 16] = vb.y, dst[2 * ALD + 16] = vb.z, dst[3 * ALD + 16] = vb.w;
                 }
-                const int k0 = kt * CBK;
-                // the weight fragments of this K-tile (L2-resident slab) and the next tile's rows: all loads in flight together
-                float bw[CBK / 2][NJ];
-#pragma unroll
-                for (int s2 = 0; s2 < CBK / 2; ++s2)
-#pragma unroll
-                    for (int jn = 0; jn < NJ; ++jn) bw[s2][jn] = wd[(long long)(k0 + 2 * s2 + half) * Cout + 32 * jn + l31];
+                // the NEXT tile's weight fragments (L2-resident slab) and rows: every load a K-tile ahead of its use
+                float bn[CBK / 2][NJ];
                 if (kt + 1 < ktiles) {
+#pragma unroll
+                    for (int s2 = 0; s2 < CBK / 2; ++s2)
+#pragma unroll
+                        for (int jn = 0; jn < NJ; ++jn) bn[s2][jn] = wd[(long long)(k0 + CBK + 2 * s2 + half) * Cout + 32 * jn + l31];
                     va = jA >= 0 ? *(const float4*)(feat + (long long)jA * ldf + k0 + CBK + ka) : make_float4(0.f, 0.f, 0.f, 0.f);
                     vb = jB >= 0 ? *(const float4*)(feat + (long long)jB * ldf + k0 + CBK + ka) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
@@ -299,6 +338,12 @@ __global__ __launch_bounds__(256) void subm_conv_compact_kernel(const float* __r
                     const float av = A[(2 * s2 + half) * ALD + l31];
 #pragma unroll
                     for (int jn = 0; jn < NJ; ++jn) acc[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bw[s2][jn], acc[jn], 0, 0, 0);
+                }
+                if (kt + 1 < ktiles) {
+#pragma unroll
+                    for (int s2 = 0; s2 < CBK / 2; ++s2)
+#pragma unroll
+                        for (int jn = 0; jn < NJ; ++jn) bw[s2][jn] = bn[s2][jn];
                 }
                 // (the other buffer is written next; this one again two tiles later, after this tile's reads were issued in order)
             }
@@ -357,7 +402,8 @@ extern "C" int pn2_ptv3_subm_neighbors_i32(const int64_t* batch, const int32_t* 
 }
 
 extern "C" int pn2_ptv3_subm_conv_f32(const float* feat, int64_t ldf, const int32_t* nbr, int kernel_size, const float* weight,
-                                      const float* bias, int N, int Cin, int Cout, float* out, int64_t ldo, void* stream) {
+                                      const void* weight_bf16, const float* bias, int N, int Cin, int Cout, float* out,
+                                      int64_t ldo, void* stream) {
     if (!feat || !nbr || !weight || !out || N <= 0 || Cin <= 0 || Cout <= 0 || Cin % CBK || Cout % 32 || ldf % 4 || ldf < Cin ||
         ldo < Cout || ((uintptr_t)feat & 15) || ((uintptr_t)weight & 15) || (kernel_size != 3 && kernel_size != 5))
         return PN2_E_BADARG;
@@ -366,15 +412,29 @@ extern "C" int pn2_ptv3_subm_conv_f32(const float* feat, int64_t ldf, const int3
     // rows compacted per offset from 128 input channels on (measured at 3.7 present neighbours, 1 M voxels: C = 128 7.0 -> 5.0 ms;
     // C = 64 2.06 -> 2.00; C = 32 0.68 -> 0.92: an item's per-K-tile round trips are not amortised by narrow rows);
     // PN2_CPE_DENSE_TILES=1 / PN2_CPE_COMPACT=1 force either kernel (A/B aid)
+    if (weight_bf16 && noff == 27 && Cin >= 64) {   // bf16 mode: the compacted kernel on bfloat16 operands (narrower layers: fp32)
+        if ((uintptr_t)weight_bf16 & 15) return PN2_E_BADARG;
+        const int ctc = Cout % 64 == 0 ? 64 : 32;
+        const dim3 gridc(pn2::ceil_div(N, CT_ROWS), Cout / ctc);
+        const double fl = 2.0 * 27.0 * N * (double)Cin * Cout, by = 4.0 * N * (27.0 + Cin + Cout) + 2.0 * 27.0 * Cin * Cout;
+        if (ctc == 64)
+            PN2_LAUNCH("ptv3_subm_conv_bf16", by, fl, (subm_conv_compact_kernel<64, true>), gridc, dim3(256), s, feat, (long long)ldf, nbr,
+                       (const float*)weight_bf16, bias, N, Cin, Cout, out, (long long)ldo);
+        else
+            PN2_LAUNCH("ptv3_subm_conv_bf16", by, fl, (subm_conv_compact_kernel<32, true>), gridc, dim3(256), s, feat, (long long)ldf, nbr,
+                       (const float*)weight_bf16, bias, N, Cin, Cout, out, (long long)ldo);
+        PN2_LAUNCH_CHECK();
+        return 0;
+    }
     if (noff == 27 && (Cin >= 128 || getenv("PN2_CPE_COMPACT")) && !getenv("PN2_CPE_DENSE_TILES")) {
         const int ctc = Cout % 64 == 0 ? 64 : 32;
         const dim3 gridc(pn2::ceil_div(N, CT_ROWS), Cout / ctc);
         const double fl = 2.0 * 27.0 * N * (double)Cin * Cout, by = 4.0 * N * (27.0 + Cin + Cout) + 4.0 * 27.0 * Cin * Cout;
         if (ctc == 64)
-            PN2_LAUNCH("ptv3_subm_conv", by, fl, (subm_conv_compact_kernel<64>), gridc, dim3(256), s, feat, (long long)ldf, nbr, weight, bias,
+            PN2_LAUNCH("ptv3_subm_conv", by, fl, (subm_conv_compact_kernel<64, false>), gridc, dim3(256), s, feat, (long long)ldf, nbr, weight, bias,
                        N, Cin, Cout, out, (long long)ldo);
         else
-            PN2_LAUNCH("ptv3_subm_conv", by, fl, (subm_conv_compact_kernel<32>), gridc, dim3(256), s, feat, (long long)ldf, nbr, weight, bias,
+            PN2_LAUNCH("ptv3_subm_conv", by, fl, (subm_conv_compact_kernel<32, false>), gridc, dim3(256), s, feat, (long long)ldf, nbr, weight, bias,
                        N, Cin, Cout, out, (long long)ldo);
         PN2_LAUNCH_CHECK();
         return 0;

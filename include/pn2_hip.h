@@ -583,12 +583,16 @@ int pn2_serialize_decode_i64(const int64_t *codes, long long N, int depth, int o
  *   C_in a multiple of 16, C_out of 32.  fp32 (v_mfma_f32_32x32x2_f32).  Forward only.
  * kernel_size 3 (the CPE: 27 offsets) or 5 (the stem of Embedding, blocks.py:783-791: 125 offsets, index
  *   (dx + 2) * 25 + (dy + 2) * 5 + (dz + 2); nbr [N][125], weight [125][C_in][C_out]); a C_in that is not a multiple of 16 (the stem's
- *   input features) is zero-padded by the caller. */
+ *   input features) is zero-padded by the caller.
+ * weight_bf16 (NULL: fp32): a __bf16 copy of the weights laid out [27][C_out][C_in] selects the bf16 mode for kernel_size 3 and
+ *   C_in >= 64: operands rounded to bfloat16, v_mfma_f32_32x32x16_bf16, fp32 accumulation, fp32 rows in and out (the throughput
+ *   mode with its own tolerance, as PN2_PRECISION_BF16 of the attention); narrower layers and the stem stay fp32. */
 size_t pn2_ptv3_subm_workspace_bytes(int N);
 int pn2_ptv3_subm_neighbors_i32(const int64_t *batch, const int32_t *grid_coord, int N, int kernel_size, int32_t *nbr,
                                 void *workspace, size_t workspace_bytes, int32_t *status, void *stream);
 int pn2_ptv3_subm_conv_f32(const float *feat, int64_t ldf, const int32_t *nbr, int kernel_size, const float *weight,
-                           const float *bias, int N, int Cin, int Cout, float *out, int64_t ldo, void *stream);
+                           const void *weight_bf16, const float *bias, int N, int Cin, int Cout, float *out, int64_t ldo,
+                           void *stream);
 
 #ifdef __cplusplus
 }

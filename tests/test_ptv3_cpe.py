@@ -126,3 +126,37 @@ def test_stem_conv_5x5x5_on_raw_features():
         out = conv(torch.from_numpy(feat).cuda(), nbr)
     want = P.subm_conv(feat, want_nbr, conv.weight.detach().cpu().numpy(), None)
     assert float((out.cpu().double() - want).abs().max()) <= 2e-6 * float(want.abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,extent,c", [(4000, 30, 64), (3000, 24, 128), (2500, 20, 256)])
+def test_subm_conv_bf16_mode(n, extent, c):
+    """bf16 mode (operands rounded to bfloat16, fp32 accumulation): within 1.5e-2 of the largest value of the float64 restatement
+    (measured 4-6e-3: ~250 products of bfloat16-rounded factors per output), and exactly the fp32 kernel's result on inputs that
+    ARE bfloat16 numbers."""
+    helpers.load_pkg()
+    from oracle import ptv3_cpe_port as P
+    from pn2_amd.PointTransformerV3 import cpe
+    batch, grid = _voxels(n, 2, extent, seed=c)
+    N = len(grid)
+    feat = np.random.default_rng(9).standard_normal((N, c)).astype(np.float32)
+    nbr = cpe.subm_neighbors(torch.from_numpy(batch).cuda(), torch.from_numpy(grid).cuda())
+    torch.manual_seed(8)
+    conv = cpe.SubMConv3d(c, c).cuda()
+    want = P.subm_conv(feat, nbr.cpu().numpy(), conv.weight.detach().cpu().numpy(), conv.bias.detach().cpu().numpy())
+    old = cpe.CONV_PRECISION
+    try:
+        cpe.CONV_PRECISION = "bf16"
+        with torch.no_grad():
+            out = conv(torch.from_numpy(feat).cuda(), nbr)
+            err = float((out.cpu().double() - want).abs().max()) / float(want.abs().max())
+            assert err <= 1.5e-2, err
+            # bfloat16-representable inputs and weights: both modes multiply the same numbers
+            conv.weight.copy_(conv.weight.to(torch.bfloat16).float())
+            fb = torch.from_numpy(feat).cuda().to(torch.bfloat16).float()
+            out16 = conv(fb, nbr)
+            cpe.CONV_PRECISION = "f32"
+            out32 = conv(fb, nbr)
+        assert float((out16 - out32).abs().max()) <= 2e-5 * float(out32.abs().max())
+    finally:
+        cpe.CONV_PRECISION = old

@@ -40,7 +40,9 @@ def main():
     from pn2_amd import _hip
     from pn2_amd.PointTransformerV3 import attention as A
     from pn2_amd.PointTransformerV3.PointTransformerV3 import PointTransformerV3
-    A.ATTENTION_PRECISION = args.precision
+    from pn2_amd.PointTransformerV3 import cpe
+    A.ATTENTION_PRECISION = args.precision        # bf16: bfloat16 MFMA operands in the patch attention and in the submanifold
+    cpe.CONV_PRECISION = args.precision           # convolutions of the layers >= 64 wide; the torch layers stay fp32
     torch.manual_seed(0)
     model = PointTransformerV3(in_channels=4).cuda().eval()
     g = plot_voxels(args.points, args.grid)
