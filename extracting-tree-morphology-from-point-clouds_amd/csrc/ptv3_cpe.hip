@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void subm_conv_compact_kernel(const float* __r
     constexpr int NJ = CT / 32, OLD = CT + 4;
     __shared__ __attribute__((aligned(16))) float O[CT_ROWS * OLD];
     __shared__ int s_nbr[CT_ROWS * 27];
-    __shared__ __attribute__((aligned(16))) float Aw[4][2][CBK * ALD];
+    __shared__ __attribute__((aligned(16))) float Aw[4][1][2 * CBK * ALD];   // per wavefront: fp32 [32 k][36] or bfloat16 [32 rows][144 B]
     __shared__ int s_rows[4][32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
     const int m0 = blockIdx.x * CT_ROWS, n0 = blockIdx.y * CT;
@@ -279,73 +279,94 @@ __global__ __launch_bounds__(256) void subm_conv_compact_kernel(const float* __r
             for (int jn = 0; jn < NJ; ++jn)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[jn][r] = 0.0f;
-            float4 va = jA >= 0 ? *(const float4*)(feat + (long long)jA * ldf + ka) : make_float4(0.f, 0.f, 0.f, 0.f);
-            float4 vb = jB >= 0 ? *(const float4*)(feat + (long long)jB * ldf + ka) : make_float4(0.f, 0.f, 0.f, 0.f);
-            bf16x8 bw16[NJ];
-            float bw[CBK / 2][NJ];
-            if constexpr (BF16) {
+            // The block's rows come KC K-tiles at a time: all of a chunk's gathers are in flight together and a chunk ahead of their
+            // use (one K-tile per round trip made the kernel latency-bound: bfloat16 operands bought only 1.37 x).  One LDS image
+            // per wavefront: its reads are issued, in order, before the next chunk's writes.
+            constexpr int KC = BF16 ? 4 : 2;                  // K-tiles per chunk (fp32: the image must stay 4.6 KB per wavefront)
+            constexpr int P16 = 2 * CBK * KC + 16;            // bfloat16 image: row pitch in bytes (16 bytes of padding)
+            const int nchunks = ktiles / KC;                  // (the launcher guarantees Cin % (16 KC) == 0)
+            float4 va[KC], vb[KC];
+            auto gather = [&](int c) {
 #pragma unroll
-                for (int jn = 0; jn < NJ; ++jn) bw16[jn] = *(const bf16x8*)(wd16 + (long long)(32 * jn + l31) * Cin + 8 * half);
-            } else {
-#pragma unroll
-                for (int s2 = 0; s2 < CBK / 2; ++s2)
-#pragma unroll
-                    for (int jn = 0; jn < NJ; ++jn) bw[s2][jn] = wd[(long long)(2 * s2 + half) * Cout + 32 * jn + l31];
-            }
-            for (int kt = 0; kt < ktiles; ++kt) {
-                float* A = Aw[wave][kt & 1];
-                const int k0 = kt * CBK;
+                for (int t = 0; t < KC; ++t) {
+                    const int k = (c * KC + t) * CBK + ka;
+                    va[t] = jA >= 0 ? *(const float4*)(feat + (long long)jA * ldf + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    vb[t] = jB >= 0 ? *(const float4*)(feat + (long long)jB * ldf + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            };
+            // ... and so do the chunk's weight fragments (L2-resident slab): bw / bw16 hold the CURRENT chunk's, loaded a chunk ago
+            bf16x8 bw16[KC][NJ], bn16[KC][NJ];
+            float bw[BF16 ? 1 : KC * CBK / 2][NJ], bn[BF16 ? 1 : KC * CBK / 2][NJ];
+            auto weights = [&](int c, bf16x8 (&w16)[KC][NJ], float (&w32)[BF16 ? 1 : KC * CBK / 2][NJ]) {
+                const int k0 = c * KC * CBK;
                 if constexpr (BF16) {
-                    char* A16 = (char*)A;
-                    *(bf16x4*)(A16 + (lane >> 2) * 48 + 2 * ka) = bf16x4{(__bf16)va.x, (__bf16)va.y, (__bf16)va.z, (__bf16)va.w};
-                    *(bf16x4*)(A16 + (16 + (lane >> 2)) * 48 + 2 * ka) = bf16x4{(__bf16)vb.x, (__bf16)vb.y, (__bf16)vb.z, (__bf16)vb.w};
-                    bf16x8 bnext[NJ];   // the NEXT tile's weight fragments and rows: every load a K-tile ahead of its use
-                    if (kt + 1 < ktiles) {
+#pragma unroll
+                    for (int t = 0; t < KC; ++t)
 #pragma unroll
                         for (int jn = 0; jn < NJ; ++jn)
-                            bnext[jn] = *(const bf16x8*)(wd16 + (long long)(32 * jn + l31) * Cin + k0 + CBK + 8 * half);
-                        va = jA >= 0 ? *(const float4*)(feat + (long long)jA * ldf + k0 + CBK + ka) : make_float4(0.f, 0.f, 0.f, 0.f);
-                        vb = jB >= 0 ? *(const float4*)(feat + (long long)jB * ldf + k0 + CBK + ka) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    }
-                    wave_lds_sync();
-                    const bf16x8 af = *(const bf16x8*)(A16 + l31 * 48 + 16 * half);
+                            w16[t][jn] = *(const bf16x8*)(wd16 + (long long)(32 * jn + l31) * Cin + k0 + t * CBK + 8 * half);
+                } else {
 #pragma unroll
-                    for (int jn = 0; jn < NJ; ++jn) acc[jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bw16[jn], acc[jn], 0, 0, 0);
-                    if (kt + 1 < ktiles) {
+                    for (int s2 = 0; s2 < KC * CBK / 2; ++s2)
 #pragma unroll
-                        for (int jn = 0; jn < NJ; ++jn) bw16[jn] = bnext[jn];
-                    }
-                    continue;
+                        for (int jn = 0; jn < NJ; ++jn) w32[s2][jn] = wd[(long long)(k0 + 2 * s2 + half) * Cout + 32 * jn + l31];
                 }
-                {
-                    float* dst = A + ka * ALD + (lane >> 2);
-                    dst[0] = va.x, dst[ALD] = va.y, dst[2 * ALD] = va.z, dst[3 * ALD] = va.w;
-                    dst[16] = vb.x, dst[ALD + 16] = vb.y, dst[2 * ALD + 16] = vb.z, dst[3 * ALD + 16] = vb.w;
+            };
+            gather(0);
+            weights(0, bw16, bw);
+            float* A = Aw[wave][0];
+            char* A16 = (char*)A;
+            for (int c = 0; c < nchunks; ++c) {
+                if constexpr (BF16) {
+#pragma unroll
+                    for (int t = 0; t < KC; ++t) {
+                        *(bf16x4*)(A16 + (lane >> 2) * P16 + 2 * (t * CBK + ka)) =
+                            bf16x4{(__bf16)va[t].x, (__bf16)va[t].y, (__bf16)va[t].z, (__bf16)va[t].w};
+                        *(bf16x4*)(A16 + (16 + (lane >> 2)) * P16 + 2 * (t * CBK + ka)) =
+                            bf16x4{(__bf16)vb[t].x, (__bf16)vb[t].y, (__bf16)vb[t].z, (__bf16)vb[t].w};
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < KC; ++t) {
+                        float* dst = A + (t * CBK + ka) * ALD + (lane >> 2);
+                        dst[0] = va[t].x, dst[ALD] = va[t].y, dst[2 * ALD] = va[t].z, dst[3 * ALD] = va[t].w;
+                        dst[16] = vb[t].x, dst[ALD + 16] = vb[t].y, dst[2 * ALD + 16] = vb[t].z, dst[3 * ALD + 16] = vb[t].w;
+                    }
                 }
-                // the NEXT tile's weight fragments (L2-resident slab) and rows: every load a K-tile ahead of its use
-                float bn[CBK / 2][NJ];
-                if (kt + 1 < ktiles) {
-#pragma unroll
-                    for (int s2 = 0; s2 < CBK / 2; ++s2)
-#pragma unroll
-                        for (int jn = 0; jn < NJ; ++jn) bn[s2][jn] = wd[(long long)(k0 + CBK + 2 * s2 + half) * Cout + 32 * jn + l31];
-                    va = jA >= 0 ? *(const float4*)(feat + (long long)jA * ldf + k0 + CBK + ka) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    vb = jB >= 0 ? *(const float4*)(feat + (long long)jB * ldf + k0 + CBK + ka) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c + 1 < nchunks) {
+                    gather(c + 1);
+                    weights(c + 1, bn16, bn);
                 }
                 wave_lds_sync();
+                if constexpr (BF16) {
 #pragma unroll
-                for (int s2 = 0; s2 < CBK / 2; ++s2) {
-                    const float av = A[(2 * s2 + half) * ALD + l31];
+                    for (int t = 0; t < KC; ++t) {
+                        const bf16x8 af = *(const bf16x8*)(A16 + l31 * P16 + 2 * t * CBK + 16 * half);
 #pragma unroll
-                    for (int jn = 0; jn < NJ; ++jn) acc[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bw[s2][jn], acc[jn], 0, 0, 0);
+                        for (int jn = 0; jn < NJ; ++jn) acc[jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bw16[t][jn], acc[jn], 0, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int s2 = 0; s2 < KC * CBK / 2; ++s2) {
+                        const float av = A[(2 * s2 + half) * ALD + l31];
+#pragma unroll
+                        for (int jn = 0; jn < NJ; ++jn) acc[jn] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bw[s2][jn], acc[jn], 0, 0, 0);
+                    }
                 }
-                if (kt + 1 < ktiles) {
+                if (c + 1 < nchunks) {
+                    if constexpr (BF16) {
 #pragma unroll
-                    for (int s2 = 0; s2 < CBK / 2; ++s2)
+                        for (int t = 0; t < KC; ++t)
 #pragma unroll
-                        for (int jn = 0; jn < NJ; ++jn) bw[s2][jn] = bn[s2][jn];
+                            for (int jn = 0; jn < NJ; ++jn) bw16[t][jn] = bn16[t][jn];
+                    } else {
+#pragma unroll
+                        for (int s2 = 0; s2 < KC * CBK / 2; ++s2)
+#pragma unroll
+                            for (int jn = 0; jn < NJ; ++jn) bw[s2][jn] = bn[s2][jn];
+                    }
                 }
-                // (the other buffer is written next; this one again two tiles later, after this tile's reads were issued in order)
+                wave_lds_sync();   // the image is rewritten by the next chunk
             }
             wave_lds_sync();
             // add the block's products to the output tile: accumulator row p = (r & 3) + 8 (r >> 2) + 4 half -> voxel s_rows[p]
@@ -412,7 +433,7 @@ extern "C" int pn2_ptv3_subm_conv_f32(const float* feat, int64_t ldf, const int3
     // rows compacted per offset from 128 input channels on (measured at 3.7 present neighbours, 1 M voxels: C = 128 7.0 -> 5.0 ms;
     // C = 64 2.06 -> 2.00; C = 32 0.68 -> 0.92: an item's per-K-tile round trips are not amortised by narrow rows);
     // PN2_CPE_DENSE_TILES=1 / PN2_CPE_COMPACT=1 force either kernel (A/B aid)
-    if (weight_bf16 && noff == 27 && Cin >= 64) {   // bf16 mode: the compacted kernel on bfloat16 operands (narrower layers: fp32)
+    if (weight_bf16 && noff == 27 && Cin >= 64 && Cin % 64 == 0) {   // bf16 mode: the compacted kernel on bfloat16 operands (narrower layers: fp32)
         if ((uintptr_t)weight_bf16 & 15) return PN2_E_BADARG;
         const int ctc = Cout % 64 == 0 ? 64 : 32;
         const dim3 gridc(pn2::ceil_div(N, CT_ROWS), Cout / ctc);
@@ -426,7 +447,7 @@ extern "C" int pn2_ptv3_subm_conv_f32(const float* feat, int64_t ldf, const int3
         PN2_LAUNCH_CHECK();
         return 0;
     }
-    if (noff == 27 && (Cin >= 128 || getenv("PN2_CPE_COMPACT")) && !getenv("PN2_CPE_DENSE_TILES")) {
+    if (noff == 27 && Cin % 32 == 0 && (Cin >= 128 || getenv("PN2_CPE_COMPACT")) && !getenv("PN2_CPE_DENSE_TILES")) {
         const int ctc = Cout % 64 == 0 ? 64 : 32;
         const dim3 gridc(pn2::ceil_div(N, CT_ROWS), Cout / ctc);
         const double fl = 2.0 * 27.0 * N * (double)Cin * Cout, by = 4.0 * N * (27.0 + Cin + Cout) + 4.0 * 27.0 * Cin * Cout;
