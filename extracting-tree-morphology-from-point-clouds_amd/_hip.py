@@ -128,13 +128,13 @@ SIGNATURES = {
     "pn2_mlp_reduce_wgrad": (_int, [ctypes.POINTER(WgradTask), _int, _vp]),
     "pn2_mlp_pair_dgrad_f32": (_int, [_int, _lp, _vp, _lp, _vp, _vp, _i64, _vp, _i64, _sp, _int, _vp]),
     "pn2_group_bn_workspace_bytes": (_sz, [_int, _int, _int, _int, _int]),
-    "pn2_group_bn_fwd_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _lp, _sp, _vp, _vp, _sz,
-                                    _vp]),
+    "pn2_group_bn_fwd_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _int, _int, _int, _int, _lp, _sp, _int, _vp, _vp,
+                                    _sz, _vp]),
     "pn2_group_bn_bwd_f32": (_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _int, _int, _int, _int, _lp, _vp, _vp, _i64, _sp, _vp, _sz,
                                     _vp]),
     "pn2_interp_bn_workspace_bytes": (_sz, [_int, ctypes.c_longlong, _int, _int, _int]),
-    "pn2_interp_bn_fwd_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, ctypes.c_longlong, _lp, _sp, _int, _vp, _vp, _sz,
-                                     _vp]),
+    "pn2_interp_bn_fwd_f32": (_int, [_vp, _vp, _vp, _vp, _vp, _int, _int, _int, ctypes.c_longlong, _lp, _sp, _int, _int, _vp, _vp,
+                                     _sz, _vp]),
     "pn2_interp_bn_bwd_f32": (_int, [_vp, _vp, _vp, _vp, _int, _int, _int, ctypes.c_longlong, _lp, _vp, _sp, _int, _vp, _sz, _vp]),
     "pn2_mlp_chain_bwd_f32": (_int, [_vp, _i64, _int, _lp, _int, _int, _vp, _vp, _vp, _i64, _int, _vp, _vp, _sp, _int, _tp, _cp, _vp,
                                      _sz, _vp]),

@@ -1875,7 +1875,7 @@ struct GroupSrc {
 
 // Y16: the rows are stored as bfloat16 (bf16 mode with bfloat16 storage; the statistics come from the fp32 registers, as in
 // the GEMM epilogue)
-template <class SRC, bool Y16 = false>
+template <class SRC, bool Y16 = false, bool STATS = true>   // STATS = false (eval mode): the rows only
 __global__ __launch_bounds__(256) void rows_stats_kernel(SRC src, int C, float* __restrict__ y, float* __restrict__ partial,
                                                          long long pchunk, long long pcol, long long pwhich, const SegTable st,
                                                          int32_t* status) {
@@ -1904,6 +1904,7 @@ __global__ __launch_bounds__(256) void rows_stats_kernel(SRC src, int C, float* 
                 }
             }
         }
+        if (!STATS) continue;
         float4 s = v[0];
 #pragma unroll
         for (int p = 1; p < IB_PASSES; ++p) s.x += v[p].x, s.y += v[p].y, s.z += v[p].z, s.w += v[p].w;
@@ -1947,6 +1948,15 @@ __global__ __launch_bounds__(256) void rows_stats_kernel(SRC src, int C, float* 
     }
 }
 
+// eval mode of the hoisted layers: the coefficient block from the running statistics (one block serves every row)
+int hoisted_eval_coef(const pn2_mlp_layer& L, hipStream_t s) {
+    if (!L.running_mean || !L.running_var) return PN2_E_BADARG;
+    PN2_LAUNCH("bn_eval_coef", 36.0 * L.cout, 0, bn_eval_coef_kernel, dim3(pn2::ceil_div(L.cout, 256)), dim3(256), s, L.cout, L.gamma,
+               L.beta, L.running_mean, L.running_var, L.eps, L.stats);
+    PN2_LAUNCH_CHECK();
+    return 0;
+}
+
 bool interp_bn_args_ok(const void* idx, const void* w, const int32_t* coff, int B, int N, int S, long long rows,
                        const pn2_mlp_layer* L, const pn2_segments* sg) {
     if (!idx || !w || !L || B <= 0 || N <= 0 || S <= 0 || rows <= 0 || rows >= (1ll << 31) / 4 || B > 65535 || S > 8192) return false;
@@ -1969,14 +1979,14 @@ extern "C" size_t pn2_interp_bn_workspace_bytes(int B, long long rows, int S, in
 
 extern "C" int pn2_interp_bn_fwd_f32(const float* q, const int32_t* idx, const float* w, const int32_t* coff,
                                      const int32_t* row_cloud, int B, int N, int S, long long nrows, const pn2_mlp_layer* layer,
-                                     const pn2_segments* segments, int rows_bf16, int32_t* status, void* workspace,
+                                     const pn2_segments* segments, int training, int rows_bf16, int32_t* status, void* workspace,
                                      size_t workspace_bytes, void* stream) {
     if (!q || !aligned16(q) || (coff == nullptr) != (row_cloud == nullptr) ||
-        !interp_bn_args_ok(idx, w, coff, B, N, S, nrows, layer, segments))
+        !interp_bn_args_ok(idx, w, coff, B, N, S, nrows, layer, training ? segments : nullptr))
         return PN2_E_BADARG;
     const pn2_mlp_layer& L = *layer;
     const int rows = (int)nrows, C = L.cout;
-    const Segs Sg = make_segs(rows, segments);
+    const Segs Sg = make_segs(rows, training ? segments : nullptr);
     if (!workspace || workspace_bytes < pn2_interp_bn_workspace_bytes(B, rows, S, C, Sg.nseg)) return PN2_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     const FinScratch fs = fin_scratch(workspace, Sg.nseg, (size_t)C);
@@ -1986,6 +1996,13 @@ extern "C" int pn2_interp_bn_fwd_f32(const float* q, const int32_t* idx, const f
     const SegTable st = make_table(Sg, R, &nblk);
     const long long cm = cm_stride(rows, R, Sg.nseg);
     const InterpSrc src{q, idx, w, row_cloud, N, S};
+    if (!training) {   // eval: rows only, coefficients from the running statistics
+        if (rows_bf16) return PN2_E_BADARG;
+        PN2_LAUNCH("interp_bn_fwd", (double)rows * (36.0 + 4.0 * C) + 4.0 * B * S * C, 0, (rows_stats_kernel<InterpSrc, false, false>),
+                   dim3(nblk), dim3(256), s, src, C, L.y, part, 0ll, 0ll, 0ll, st, status);
+        PN2_LAUNCH_CHECK();
+        return hoisted_eval_coef(L, s);
+    }
     if (rows_bf16)
         PN2_LAUNCH("interp_bn_fwd", (double)rows * (36.0 + 2.0 * C) + 4.0 * B * S * C, 0, (rows_stats_kernel<InterpSrc, true>), dim3(nblk),
                    dim3(256), s, src, C, L.y, part, cm ? 2ll : 2ll * C, cm ? cm : 1ll, cm ? 1ll : (long long)C, st, status);
@@ -2173,12 +2190,13 @@ extern "C" size_t pn2_group_bn_workspace_bytes(int B, int S, int K, int C, int n
 
 extern "C" int pn2_group_bn_fwd_f32(const float* gf, const float* xyz, int64_t sb, int64_t sn, int64_t sc, const float* new_xyz,
                                     const int32_t* idx, const float* wx, int64_t ldw, int B, int N, int S, int K,
-                                    const pn2_mlp_layer* layer, const pn2_segments* segments, int32_t* status, void* workspace,
-                                    size_t workspace_bytes, void* stream) {
-    if (!gf || !aligned16(gf) || !wx || !group_bn_args_ok(xyz, new_xyz, idx, B, N, S, K, layer, segments)) return PN2_E_BADARG;
+                                    const pn2_mlp_layer* layer, const pn2_segments* segments, int training, int32_t* status,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+    if (!gf || !aligned16(gf) || !wx || !group_bn_args_ok(xyz, new_xyz, idx, B, N, S, K, layer, training ? segments : nullptr))
+        return PN2_E_BADARG;
     const pn2_mlp_layer& L = *layer;
     const int rows = B * S * K, C = L.cout;
-    const Segs Sg = make_segs(rows, segments);
+    const Segs Sg = make_segs(rows, training ? segments : nullptr);
     if (!workspace || workspace_bytes < pn2_group_bn_workspace_bytes(B, S, K, C, Sg.nseg)) return PN2_E_WORKSPACE;
     hipStream_t s = (hipStream_t)stream;
     const FinScratch fs = fin_scratch(workspace, Sg.nseg, (size_t)C);
@@ -2190,6 +2208,12 @@ extern "C" int pn2_group_bn_fwd_f32(const float* gf, const float* xyz, int64_t s
     GroupSrc src{};
     src.gf = gf, src.xyz = xyz, src.sb = sb, src.sn = sn, src.sc = sc, src.new_xyz = new_xyz, src.wx = wx, src.ldw = ldw;
     src.idx = idx, src.N = N, src.S = S, src.K = K;
+    if (!training) {
+        PN2_LAUNCH("group_bn_fwd", (double)rows * (8.0 * C + 20.0), 6.0 * rows * C, (rows_stats_kernel<GroupSrc, false, false>), dim3(nblk),
+                   dim3(256), s, src, C, L.y, part, 0ll, 0ll, 0ll, st, status);
+        PN2_LAUNCH_CHECK();
+        return hoisted_eval_coef(L, s);
+    }
     PN2_LAUNCH("group_bn_fwd", (double)rows * (8.0 * C + 20.0), 6.0 * rows * C, (rows_stats_kernel<GroupSrc>), dim3(nblk), dim3(256), s,
                src, C, L.y, part, cm ? 2ll : 2ll * C, cm ? cm : 1ll, cm ? 1ll : (long long)C, st, status);
     PN2_LAUNCH_CHECK();

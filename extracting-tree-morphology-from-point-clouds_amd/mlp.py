@@ -469,9 +469,10 @@ class _InterpBNFn(torch.autograd.Function):
         N = rc.n_max if rc is not None else rows // B
         dev = q.device
         q = _hip.f32(q).contiguous()
-        seg_ptr, seg_keep = _hip.segments_arg(meta.get("seg_off"))
+        training = bool(meta["training"])
+        seg_ptr, seg_keep = _hip.segments_arg(meta.get("seg_off") if training else None)
         nseg = 1 if seg_ptr is None else len(meta["seg_off"]) - 1
-        y16 = bool(meta.get("rows_bf16"))              # bf16 mode with bfloat16 storage: the linked chain keeps bfloat16 rows
+        y16 = bool(meta.get("rows_bf16")) and training  # bf16 mode with bfloat16 storage: the linked chain keeps bfloat16 rows
         y = torch.empty(rows, C, dtype=torch.bfloat16 if y16 else torch.float32, device=dev)
         st = torch.empty(8 * nseg, C, dtype=torch.float32, device=dev)
         L = _hip.MLPLayer()
@@ -484,8 +485,8 @@ class _InterpBNFn(torch.autograd.Function):
         ws = torch.empty(lib.pn2_interp_bn_workspace_bytes(B, rows, S, C, nseg), dtype=torch.uint8, device=dev)
         _hip.call("interp_bn_fwd", lib.pn2_interp_bn_fwd_f32, q.data_ptr(), idx32.data_ptr(), w.data_ptr(),
                   None if rc is None else rc.coff.data_ptr(), None if rc is None else rc.row_cloud.data_ptr(), B, N, S, rows,
-                  ctypes.byref(L), seg_ptr, int(y16), ops.status_word(dev).data_ptr(), ws.data_ptr(), ws.numel(), _hip.stream_ptr(),
-                  nbytes=rows * (36 + (2 if y16 else 4) * C) + 4 * B * S * C)
+                  ctypes.byref(L), seg_ptr, int(training), int(y16), ops.status_word(dev).data_ptr(), ws.data_ptr(), ws.numel(),
+                  _hip.stream_ptr(), nbytes=rows * (36 + (2 if y16 else 4) * C) + 4 * B * S * C)
         ctx.save_for_backward(idx32, w, y, st, gamma, beta, bias)
         ctx.meta, ctx.layer, ctx.dims = meta, L, (B, N, S, C, nseg, rows)
         ctx.mark_non_differentiable(st)
@@ -494,6 +495,8 @@ class _InterpBNFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout, _):
         lib = _hip.lib()
+        if not ctx.meta["training"]:
+            raise NotImplementedError("backward through eval-mode BatchNorm is not part of the hot path")
         idx32, w, y, st, gamma, beta, bias = ctx.saved_tensors
         B, N, S, C, nseg, rows = ctx.dims
         meta, L, dev = ctx.meta, ctx.layer, dout.device
@@ -539,7 +542,8 @@ class _GroupBNFn(torch.autograd.Function):
         gf = _hip.f32(gf).contiguous()
         xyz, new_xyz = _hip.f32(xyz), _hip.f32(new_xyz).contiguous()
         weight = weight if weight.stride(1) == 1 else weight.contiguous()
-        seg_ptr, seg_keep = _hip.segments_arg(meta.get("seg_off"))
+        training = bool(meta["training"])
+        seg_ptr, seg_keep = _hip.segments_arg(meta.get("seg_off") if training else None)
         nseg = 1 if seg_ptr is None else len(meta["seg_off"]) - 1
         y = torch.empty(rows, C, dtype=torch.float32, device=dev)
         st = torch.empty(8 * nseg, C, dtype=torch.float32, device=dev)
@@ -553,7 +557,7 @@ class _GroupBNFn(torch.autograd.Function):
         ws = torch.empty(lib.pn2_group_bn_workspace_bytes(B, S, K, C, nseg), dtype=torch.uint8, device=dev)
         xs = (xyz.stride(0), xyz.stride(1), xyz.stride(2))
         _hip.call("group_bn_fwd", lib.pn2_group_bn_fwd_f32, gf.data_ptr(), xyz.data_ptr(), *xs, new_xyz.data_ptr(), idx32.data_ptr(),
-                  weight.data_ptr() + 4 * int(meta["xcol"]), weight.stride(0), B, N, S, K, ctypes.byref(L), seg_ptr,
+                  weight.data_ptr() + 4 * int(meta["xcol"]), weight.stride(0), B, N, S, K, ctypes.byref(L), seg_ptr, int(training),
                   ops.status_word(dev).data_ptr(), ws.data_ptr(), ws.numel(), _hip.stream_ptr(),
                   nbytes=rows * (8 * C + 20), flops=6 * rows * C)
         ctx.save_for_backward(xyz, new_xyz, idx32, y, st, gamma, beta, bias)
@@ -564,6 +568,8 @@ class _GroupBNFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout, _):
         lib = _hip.lib()
+        if not ctx.meta["training"]:
+            raise NotImplementedError("backward through eval-mode BatchNorm is not part of the hot path")
         xyz, new_xyz, idx32, y, st, gamma, beta, bias = ctx.saved_tensors
         B, N, S, K, C, nseg = ctx.dims
         meta, L, dev = ctx.meta, ctx.layer, dout.device
@@ -617,7 +623,7 @@ def _bn_meta(bn, relu, seg_off, leaves):
     """BatchNorm bookkeeping shared by the hoisted-layer functions -> meta; bumps num_batches_tracked."""
     bump = []
     meta = {"relu": bool(relu), "eps": float(bn.eps), "momentum": _bn_momentum(bn, bump), "running_mean": None,
-            "running_var": None, "leaves": leaves, "lazy_handle": {}}
+            "running_var": None, "leaves": leaves, "lazy_handle": {}, "training": bn.training or bn.running_mean is None}
     if bn.track_running_stats and bn.running_mean is not None:
         meta["running_mean"], meta["running_var"] = bn.running_mean, bn.running_var
     nseg = 1
@@ -637,8 +643,8 @@ def _bn_meta(bn, relu, seg_off, leaves):
 def group_hoist_ok(conv, bn, n_layers, B, N, S, K, D, device):
     """May a set-abstraction level run the feature share of its first conv on the source points?  (Not the first level: its few
     input features are no contraction worth moving, and in whole-tree execution its clouds are ragged.)"""
-    return (D > 0 and n_layers >= 2 and device.type == "cuda" and GEMM_PRECISION == "f32" and bn is not None and bn.training
-            and conv.out_channels in HOIST_GROUP_WIDTHS and K <= 64 and S * K > N and D % 4 == 0 and D >= 32
+    return (D > 0 and n_layers >= 2 and device.type == "cuda" and GEMM_PRECISION == "f32" and bn is not None
+            and (bn.training or bn.running_mean is not None) and conv.out_channels in HOIST_GROUP_WIDTHS and K <= 64 and S * K > N and D % 4 == 0 and D >= 32
             and B * S * K >= int(os.environ.get("PN2_HOIST_GROUP_MIN_ROWS", HOIST_GROUP_MIN_ROWS))
             and not os.environ.get("PN2_NO_HOIST") and not os.environ.get("PN2_NO_HOIST_GROUP")
             and not os.environ.get("PN2_NO_LAZY_ROWS"))
@@ -676,7 +682,7 @@ def hoisted_conv(rows, conv):
 
 def hoist_ok(conv, bn, n_layers, device):
     """May a feature-propagation level without a skip connection run its first conv in front of the interpolation?"""
-    return (n_layers >= 2 and device.type == "cuda" and bn is not None and bn.training
+    return (n_layers >= 2 and device.type == "cuda" and bn is not None and (bn.training or bn.running_mean is not None)
             and conv.out_channels in HOIST_WIDTHS and not os.environ.get("PN2_NO_HOIST")
             and not os.environ.get("PN2_NO_LAZY_ROWS"))
 

@@ -446,11 +446,13 @@ int pn2_mlp_pair_dgrad_f32(int rows, const pn2_mlp_layer *la, const float *dza, 
  * Rounding: the same products summed in another order (~1e-7 relative); `segments` as for the chains, every segment made
  * of whole clouds.  rows_bf16 (bf16 mode with bfloat16 storage, PN2_CHAIN_STORE_BF16): y is written -- and y and dout are
  * read -- as __bf16 rows, so that the linked chain keeps its bfloat16 rows; q, dq, statistics and sums stay fp32.
+ * training = 0 (eval mode, both *_bn_fwd entry points): the rows only; layer->stats gets ONE coefficient block from the running
+ * statistics (segments ignored, as in the chains); fp32 rows.
  * workspace: pn2_interp_bn_workspace_bytes() for either direction. */
 size_t pn2_interp_bn_workspace_bytes(int B, long long rows, int S, int C, int nseg);
 int pn2_interp_bn_fwd_f32(const float *q, const int32_t *idx, const float *w, const int32_t *coff, const int32_t *row_cloud,
                           int B, int N, int S, long long rows, const pn2_mlp_layer *layer, const pn2_segments *segments,
-                          int rows_bf16, int32_t *status, void *workspace, size_t workspace_bytes, void *stream);
+                          int training, int rows_bf16, int32_t *status, void *workspace, size_t workspace_bytes, void *stream);
 int pn2_interp_bn_bwd_f32(const float *dout, const int32_t *idx, const float *w, const int32_t *coff, int B, int N, int S,
                           long long rows, const pn2_mlp_layer *layer, float *dq, const pn2_segments *segments,
                           int rows_bf16, void *workspace, size_t workspace_bytes, void *stream);
@@ -476,7 +478,7 @@ int pn2_interp_bn_bwd_f32(const float *dout, const int32_t *idx, const float *w,
 size_t pn2_group_bn_workspace_bytes(int B, int S, int K, int C, int nseg);
 int pn2_group_bn_fwd_f32(const float *gf, const float *xyz, int64_t sb, int64_t sn, int64_t sc, const float *new_xyz,
                          const int32_t *idx, const float *wx, int64_t ldw, int B, int N, int S, int K,
-                         const pn2_mlp_layer *layer, const pn2_segments *segments, int32_t *status, void *workspace,
+                         const pn2_mlp_layer *layer, const pn2_segments *segments, int training, int32_t *status, void *workspace,
                          size_t workspace_bytes, void *stream);
 int pn2_group_bn_bwd_f32(const float *dout, const float *xyz, int64_t sb, int64_t sn, int64_t sc, const float *new_xyz,
                          const int32_t *idx, int B, int N, int S, int K, const pn2_mlp_layer *layer, float *dgf, float *dwx,

@@ -351,3 +351,80 @@ def test_pair_dgrad_as_one_contraction(linked, segments, precision):
     tol = 2e-5 if precision == "f32" else 2e-2
     for g, h in zip(res["fused"], res["two_launches"]):
         assert float((g.float() - h.float()).norm()) <= tol * float(h.float().norm()) + 1e-7, (float((g - h).norm()), float(h.norm()))
+
+
+def test_hoisted_layers_in_eval_mode():
+    """Inference (running statistics): the hoisted feature-propagation level and the hoisted set-abstraction level against their
+    plain paths, and the whole depth-5 model's eval forward hoisted vs not."""
+    helpers.load_pkg()
+    from pn2_amd import _hip
+    from pn2_amd.PointNet2.PointNet2 import PointNet2
+    from pn2_amd.PointNet2.blocks import PointNetSetAbstraction
+    g = torch.Generator().manual_seed(12)
+
+    def randomise(mod):
+        with torch.no_grad():
+            for m in mod.modules():
+                if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                    m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.2)
+                    m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+                    m.weight.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+                    m.bias.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+
+    def run(fn, hoist, **extra):
+        names, orig = [], _hip.call
+
+        def spy(name, f, *a, **k):
+            names.append(name)
+            return orig(name, f, *a, **k)
+
+        _hip.call = spy
+        try:
+            with env(**(dict(extra) if hoist else {"PN2_NO_HOIST": 1})), torch.no_grad():
+                out = fn()
+        finally:
+            _hip.call = orig
+        torch.cuda.synchronize()
+        return out, names
+
+    fp = _fp(128, [128, 128, 128]).eval()
+    randomise(fp)
+    xyz1, xyz2, p2 = _inputs(2, 5000, 64, 128)
+    a, na = run(lambda: fp(xyz1, xyz2, None, p2), True)
+    b, nb = run(lambda: fp(xyz1, xyz2, None, p2), False)
+    assert "interp_bn_fwd" in na and "interp_bn_fwd" not in nb
+    _close(a, b, 2e-5, "eval feature propagation, hoisted vs plain")
+    with pytest.raises(NotImplementedError):      # no backward through eval-mode BatchNorm, hoisted or not
+        with env():
+            fp(xyz1, xyz2, None, p2.clone().requires_grad_(True)).sum().backward()
+
+    torch.manual_seed(21)
+    sa = PointNetSetAbstraction(64, 0.3, 32, 64 + 3, [64, 64, 128], False).cuda().eval()
+    randomise(sa)
+    xyz = (torch.rand(3, 3, 400, generator=g) + 3.0).cuda()
+    pts = torch.randn(3, 64, 400, generator=g).cuda()
+
+    def sa_run():
+        torch.manual_seed(4)
+        return sa(xyz, pts)[1]
+
+    a, na = run(sa_run, True, PN2_HOIST_GROUP_MIN_ROWS=1)
+    b, nb = run(sa_run, False)
+    assert "group_bn_fwd" in na and "group_bn_fwd" not in nb
+    _close(a, b, 3e-5, "eval set abstraction, hoisted vs plain")
+
+    torch.manual_seed(0)
+    model = PointNet2(depth=5).cuda().eval()
+    randomise(model)
+    from pn2_amd.synthetic import gaussian_branch_tree
+    xyz = torch.from_numpy(gaussian_branch_tree(16384, seed=1)[0].T[None].copy()).cuda()
+    batch = {"coords": xyz, "feats": torch.ones(1, 4, 16384).cuda(), "masks_pad": torch.ones(1, 16384, dtype=torch.bool).cuda()}
+
+    def model_run():
+        torch.manual_seed(5)
+        return model(batch, return_loss=False)["offset_predictions"]
+
+    a, na = run(model_run, True)
+    b, nb = run(model_run, False)
+    assert "interp_bn_fwd" in na
+    _close(a, b, 2e-5, "eval model offsets, hoisted vs plain")
