@@ -526,7 +526,8 @@ __global__ __launch_bounds__(256) void maxpool_scatter_sums_kernel(const float* 
                                                                    const float* __restrict__ coef, int relu,
                                                                    float* __restrict__ dz, float* __restrict__ partial,
                                                                    const SegTable st, float* __restrict__ lead, long long ldlead,
-                                                                   int nlead) {
+                                                                   int nlead, unsigned char* __restrict__ arg8) {
+    // arg8: the consumers rebuild dz themselves (TR_DYP operands, mlp_tile.h) -- no dense dz; the arg-max rows go out as bytes
     __shared__ float red[2][256];
     const RowBlock rb = row_block(st, (int)blockIdx.x, R);
     const int r0 = rb.row0, r1 = r0 + R < rb.row_end ? r0 + R : rb.row_end;
@@ -554,7 +555,9 @@ __global__ __launch_bounds__(256) void maxpool_scatter_sums_kernel(const float* 
                     s1 += gz;
                     s2 += gz * ((yy - mean) * is);
                 }
-                for (int k = 0; k < K; ++k) dz[(base + k) * C + c] = k == ka ? g : 0.0f;
+                if (arg8) arg8[(long long)gi * C + c] = (unsigned char)ka;
+                else
+                    for (int k = 0; k < K; ++k) dz[(base + k) * C + c] = k == ka ? g : 0.0f;
             }
         }
         red[0][threadIdx.x] = s1;
@@ -1113,6 +1116,24 @@ int launch_gemm(GemmArgs& g, const Segs& S, int tile, hipStream_t s, int* nblk_o
                : launch_gemm_tv<A_T, A_KIND, B_T, B_KIND, EPI, 64, false>(g, S, s, nblk_out);
 }
 
+// The pooled layer's weight / input gradient with the max-pool's gradient rebuilt while staging (TR_DYP): fp32 rows, 16-byte
+// staging, the 128- and the plain 64-tile kernels only -- pooled_dyp_ok() below is the same test, made before the scatter
+template <bool A_T, bool B_T, int B_KIND, int EPI>
+int launch_gemm_dyp(GemmArgs& g, const Segs& S, int tile, hipStream_t s, int* nblk_out = nullptr) {
+    if (!(vec_ok(g.A) && vec_ok(g.B)) || g.A.p16 || g.B.p16 || g.c16 || g.ey16) return PN2_E_BADARG;
+    if (tile == 128 && g.precision == PN2_PRECISION_BF16)
+        return launch_gemm_tv<A_T, TR_DYP, B_T, B_KIND, EPI, 128, true, 1, true>(g, S, s, nblk_out);
+    if (tile == 128) return launch_gemm_tv<A_T, TR_DYP, B_T, B_KIND, EPI, 128, true>(g, S, s, nblk_out);
+    return launch_gemm_tv<A_T, TR_DYP, B_T, B_KIND, EPI, 64, true>(g, S, s, nblk_out);
+}
+// would launch_gemm pick one of those kernels for this problem?  (the small-problem variants -- 32-tiles, K teams -- keep dz)
+inline bool dyp_tile_ok(int tile, int M, int N, int K, int epi, int nseg) {
+    if (tile == 128) return true;
+    if (epi != EPI_SLAB && K >= 8 * BK && (long long)grid_blocks(M, N, 64) <= 512) return false;
+    (void)nseg;
+    return true;
+}
+
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 template <int KL>
@@ -1554,6 +1575,7 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
     float* bufs[2] = {scratch_a, scratch_b};
     int which = 0;
     int pooled_R = 0;   // > 0: the max-pool scatter left the pooled layer's BatchNorm-backward sums, row blocks of this size
+    bool pooled_dyp = false;   // ... and no dense dz: bufs[0] holds the arg-max rows as bytes, the pooled layer's GEMMs rebuild dz
     if (pool_k > 1) {
         if (!pool_arg) return PN2_E_BADARG;
         const pn2_mlp_layer& PL = layers[nlayers - 1];
@@ -1568,9 +1590,30 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
             pooled_R = gpb * pool_k;
             int nblk = 0;
             const SegTable tb = make_table(S, pooled_R, &nblk);
-            PN2_LAUNCH("maxpool_scatter", 4.0 * rows * C + 16.0 * (rows / pool_k) * C, 0, maxpool_scatter_sums_kernel, dim3(nblk),
-                       dim3(256), s, dout, pool_arg, pool_k, C, pooled_R, (const float*)PL.y, (const float*)PL.stats, PL.relu,
-                       bufs[which], ws, tb, zero_lead ? dx : nullptr, (long long)lddx, zero_lead ? dx_first_col : 0);
+            // no dense dz at all when both GEMMs of the pooled layer can rebuild it while staging (TR_DYP, mlp_tile.h)
+            {
+                const bool need_dx = nlayers > 1 || dx != nullptr;
+                const int skip = nlayers == 1 ? dx_first_col : 0;
+                const long long in_ld = nlayers == 1 ? ldx : layers[nlayers - 2].cout;
+                const float* in_p = nlayers == 1 ? x : layers[nlayers - 2].y;
+                const bool pow2 = (pool_k & (pool_k - 1)) == 0;
+                bool ok = pow2 && pool_k <= 256 && C % 4 == 0 && !dout16 && !s16 && !(nlayers == 1 && x16) && aligned16(dout) &&
+                          aligned16(PL.y) && in_ld % 4 == 0 && PL.cin % 4 == 0 && aligned16(in_p) && aligned16(PL.weight) &&
+                          skip % 4 == 0 && !getenv("PN2_NO_POOL_DYP");
+                // (a deep level's GEMMs are latency-bound: the extra address arithmetic costs them more than the dense tensor's
+                // bytes -- measured on the headline step, whose pooled chains have <= 32 768 rows: 3.94 -> 4.09 ms with it)
+                long long min_rows = 65536;
+                if (const char* e = getenv("PN2_POOL_DYP_MIN_ROWS")) min_rows = atoll(e);
+                if (rows < min_rows) ok = false;
+                if (ok && PL.dweight) ok = dyp_tile_ok(plan_wgrad(rows, PL.cout, PL.cin, S.nseg).tile, PL.cout, PL.cin, rows, EPI_SLAB, S.nseg);
+                if (ok && need_dx) ok = dyp_tile_ok(pick_tile(rows, PL.cin - skip, 1), rows, PL.cin - skip, PL.cout, EPI_STORE, S.nseg);
+                if (ok && need_dx && nlayers == 1 && (lddx % 4 != 0 || !aligned16(dx))) ok = false;
+                pooled_dyp = ok;
+            }
+            PN2_LAUNCH("maxpool_scatter", (pooled_dyp ? 0.0 : 4.0 * rows * C) + 17.0 * (rows / pool_k) * C, 0, maxpool_scatter_sums_kernel,
+                       dim3(nblk), dim3(256), s, dout, pool_arg, pool_k, C, pooled_R, (const float*)PL.y, (const float*)PL.stats,
+                       PL.relu, bufs[which], ws, tb, zero_lead ? dx : nullptr, (long long)lddx, zero_lead ? dx_first_col : 0,
+                       pooled_dyp ? (unsigned char*)bufs[which] : (unsigned char*)nullptr);
             zero_lead = false;
         } else {
             PN2_LAUNCH("maxpool_scatter", 4.0 * rows * C + 8.0 * (rows / pool_k) * C, 0, maxpool_scatter_kernel,
@@ -1674,6 +1717,12 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
             dy.cstride = L.cout;
             dy.relu = L.relu;
         }
+        const bool dyp = last && pooled_dyp;
+        if (dyp) {
+            dy.p = dout;
+            dy.parg8 = (const unsigned char*)dz;
+            dy.pool_shift = __builtin_ctz((unsigned)pool_k);
+        }
         // ---- wgrad: dW[cout][cin] += dY^T X, reduction over rows split across blocks
         if (L.dweight) {
             const WgradPlan wp = plan_wgrad(rows, L.cout, L.cin, S.nseg);
@@ -1688,7 +1737,10 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
             g.ldc = L.cin;
             g.k_per_split = wp.kps;
             int st, nsplit = 0;
-            if (L.has_bn)
+            if (dyp)
+                st = in.coef ? launch_gemm_dyp<false, false, TR_BNRELU, EPI_SLAB>(g, S, wp.tile, s, &nsplit)
+                             : launch_gemm_dyp<false, false, TR_PLAIN, EPI_SLAB>(g, S, wp.tile, s, &nsplit);
+            else if (L.has_bn)
                 st = in.coef ? launch_gemm<false, TR_DY, false, TR_BNRELU, EPI_SLAB>(g, S, wp.tile, s, &nsplit)
                              : launch_gemm<false, TR_DY, false, TR_PLAIN, EPI_SLAB>(g, S, wp.tile, s, &nsplit);
             else
@@ -1745,7 +1797,8 @@ extern "C" int pn2_mlp_chain_bwd_f32(const float* x, int64_t ldx, int rows, cons
                 g.erelu = in.relu;
                 g.pstride = cm_stride(rows, tile, S.nseg);
             }
-            int st = L.has_bn ? launch_gemm<true, TR_DY, false, TR_PLAIN, EPI_STORE>(g, S, tile, s)
+            int st = dyp      ? launch_gemm_dyp<true, false, TR_PLAIN, EPI_STORE>(g, S, tile, s)
+                     : L.has_bn ? launch_gemm<true, TR_DY, false, TR_PLAIN, EPI_STORE>(g, S, tile, s)
                               : launch_gemm<true, TR_PLAIN, false, TR_PLAIN, EPI_STORE>(g, S, tile, s);
             if (st) return st;
             dz = target;

@@ -19,7 +19,7 @@ constexpr int BK = 16, NT = 256;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
-enum { TR_PLAIN = 0, TR_BNRELU = 1, TR_DY = 2 };
+enum { TR_PLAIN = 0, TR_BNRELU = 1, TR_DY = 2, TR_DYP = 3 };   // TR_DYP: TR_DY whose dz is the max-pool's gradient, rebuilt per element
 
 // Diagnostic build (tools/build_diag.sh, -DPN2_GEMM_DIAG): wave 0 of every workgroup of the one-tile-per-workgroup kernels
 // stamps the shader clock at its phases into g_gemm_diag[linear workgroup][slot] (slot 0: 100 MHz wall clock at entry, 1..4:
@@ -61,6 +61,12 @@ struct Operand {
     int cstride;
     int relu;
     int p16, q16;       // bf16 mode with bfloat16 STORAGE: p / q point to __bf16 rows (ld / ldq still count elements)
+    // TR_DYP: the layer's output is max-pooled over groups of 2^pool_shift consecutive rows; p = the POOLED gradient
+    // [rows >> pool_shift][cols] (ld = cols), parg8 = the arg-max row of every (group, channel) as ONE BYTE, same shape:
+    //   dz[r][c] = (parg8[r >> shift][c] == (r & mask)) ? p[r >> shift][c] : 0
+    // -- the dense scattered tensor (31/32 zeros at 32 rows per group) is never written or read
+    const unsigned char* parg8;
+    int pool_shift;
 };
 
 // Branch-free tile loads: the address is clamped into the matrix and the value masked afterwards, so that all of
@@ -170,6 +176,7 @@ struct Stager {
     static constexpr int KPP = THREADS / OQ; // D layout: k-rows per pass
     static constexpr int LD = TILE + 4;
     float4 v[NP], y[NP];
+    unsigned parg[KIND == TR_DYP ? NP : 1];   // TR_DYP: the arg-max rows (one byte each) of the pass's four channels
     float cm[4], cs[4], cb[4], ca[4], cq[4];
     int tid;  // thread index inside the 256-thread team that stages this tile
 
@@ -189,7 +196,7 @@ struct Stager {
             cm[0] = m4.x; cm[1] = m4.y; cm[2] = m4.z; cm[3] = m4.w;
             cs[0] = s4.x; cs[1] = s4.y; cs[2] = s4.z; cs[3] = s4.w;
             cb[0] = b4.x; cb[1] = b4.y; cb[2] = b4.z; cb[3] = b4.w;
-            if (KIND == TR_DY) {
+            if (KIND == TR_DY || KIND == TR_DYP) {
                 const float4 a4 = *(const float4*)(o.coef + ST_A * o.cstride + cc);
                 const float4 q4 = *(const float4*)(o.coef + ST_B * o.cstride + cc);
                 ca[0] = a4.x; ca[1] = a4.y; ca[2] = a4.z; ca[3] = a4.w;
@@ -203,7 +210,7 @@ struct Stager {
             cm[j] = o.coef[ST_MEAN * o.cstride + ch];
             cs[j] = o.coef[ST_SCALE * o.cstride + ch];
             cb[j] = o.coef[ST_BETA * o.cstride + ch];
-            if (KIND == TR_DY) {
+            if (KIND == TR_DY || KIND == TR_DYP) {
                 ca[j] = o.coef[ST_A * o.cstride + ch];
                 cq[j] = o.coef[ST_B * o.cstride + ch];
             }
@@ -225,6 +232,19 @@ struct Stager {
                                   // the loads of a K-tile would serialise their round trips)
                 v[p] = ld4h<VEC>(o.p, o.ld, r, c, o.rows, o.cols);
                 if (KIND == TR_DY) y[p] = ld4h<VEC>(o.q, o.ldq, r, c, o.rows, o.cols);
+            } else if (KIND == TR_DYP) {
+                const int rr = r < o.rows ? r : o.rows - 1, gr = rr >> o.pool_shift;
+                v[p] = ld4<VEC>(o.p, o.ld, gr, c, gr + 1, o.cols);
+                if (VEC) {
+                    const int cc = c < o.cols ? c : o.cols - 4;
+                    parg[p] = *(const unsigned*)(o.parg8 + (long long)gr * o.cols + cc);
+                } else {
+                    const unsigned char* a = o.parg8 + (long long)gr * o.cols;
+                    const int last = o.cols - 1;
+                    parg[p] = (unsigned)a[c < last ? c : last] | ((unsigned)a[c + 1 < last ? c + 1 : last] << 8) |
+                              ((unsigned)a[c + 2 < last ? c + 2 : last] << 16) | ((unsigned)a[c + 3 < last ? c + 3 : last] << 24);
+                }
+                y[p] = ld4<VEC>(o.q, o.ldq, r, c, o.rows, o.cols);
             } else {
                 v[p] = ld4<VEC>(o.p, o.ld, r, c, o.rows, o.cols);
                 if (KIND == TR_DY) y[p] = ld4<VEC>(o.q, o.ldq, r, c, o.rows, o.cols);
@@ -252,7 +272,8 @@ struct Stager {
         for (int j = 0; j < 4; ++j) {
             // elements outside the matrix must be exactly zero: they pad the contraction
             const bool in = r < o.rows && c + j < o.cols;
-            w[j] = in ? xf(e[j], KIND == TR_DY ? yy[j] : 0.0f, j, o.relu) : 0.0f;
+            const float ej = KIND == TR_DYP ? (((parg[p] >> (8 * j)) & 0xFFu) == (unsigned)(r & ((1 << o.pool_shift) - 1)) ? e[j] : 0.0f) : e[j];
+            w[j] = in ? xf(ej, (KIND == TR_DY || KIND == TR_DYP) ? yy[j] : 0.0f, j, o.relu) : 0.0f;
         }
         if (IMG16) {
             char* S16 = (char*)S;

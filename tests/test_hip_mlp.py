@@ -64,6 +64,7 @@ def rel(a, b):
     (32 * 37, 67, [64, 64, 128], 32, True, nn.Conv2d, nn.BatchNorm2d),       # ragged rows, cin = 64 + 3
     (16 * 8, 259, [256, 256, 512], 16, True, nn.Conv2d, nn.BatchNorm2d),     # wide, multi-tile N and K
     (32 * 1024, 7, [32, 32, 64], 32, True, nn.Conv2d, nn.BatchNorm2d),       # SA1 of the depth-4 table: 128 scatter blocks
+    (32 * 512, 67, [128, 128, 256], 32, True, nn.Conv2d, nn.BatchNorm2d),     # pooled layer on the 128-tile kernels (TR_DYP)
     (20 * 53, 67, [64, 64, 128], 20, True, nn.Conv2d, nn.BatchNorm2d),       # K = min(nsample, N) when a cloud is small
     (5000, 128, [128, 128, 128], 1, True, nn.Conv1d, nn.BatchNorm1d),        # FP1-like
     (3001, 128, [128, 3], 1, False, nn.Conv1d, nn.BatchNorm1d),              # ConvHead: last conv bare, cout = 3
@@ -107,6 +108,45 @@ def test_pooled_chain_two_pass_sums(chain_rows, monkeypatch):
     monkeypatch.setenv("PN2_POOL_NO_SUMS", "1")
     test_chain_forward_backward(chain_rows, 32 * 100, 7, [32, 32, 64], 32, True, nn.Conv2d, nn.BatchNorm2d)
     test_chain_forward_backward(chain_rows, 16 * 8, 259, [256, 256, 512], 16, True, nn.Conv2d, nn.BatchNorm2d)
+
+
+@pytest.mark.parametrize("rows,cin,widths,pool_k,mode", [
+    (32 * 1024, 7, [32, 32, 64], 32, "f32"),       # 64-tile kernels
+    (32 * 512, 67, [128, 128, 256], 32, "f32"),    # 128-tile kernels
+    (32 * 512, 67, [128, 128, 256], 32, "bf16"),   # ... with bfloat16 MFMA operands (fp32 rows)
+    (16 * 700, 36, [64], 16, "f32"),               # the pooled layer is the chain's first: dx straight from the rebuilt gradient
+])
+def test_pooled_gradient_rebuilt_while_staging_equals_dense_scatter(chain_rows, monkeypatch, rows, cin, widths, pool_k, mode):
+    """TR_DYP (mlp_tile.h): the pooled layer's wgrad / dgrad rebuild the max-pool's gradient from (dout, arg-max bytes) instead
+    of reading the dense scattered tensor.  Same values enter the same contractions in the same order: bit-identical
+    gradients to the scatter path (PN2_NO_POOL_DYP=1)."""
+    import pn2_amd.mlp as M
+    monkeypatch.setenv("PN2_BF16_STORAGE", "0")
+    monkeypatch.setenv("PN2_POOL_DYP_MIN_ROWS", "1")   # (the default leaves the small, latency-bound levels on the dense path)
+    layers = build(widths, cin, nn.Conv2d, nn.BatchNorm2d, seed=5)
+    for c_, b_, _ in layers:
+        c_.cuda()
+        b_.cuda().train()
+    x0 = torch.randn(rows, cin, device="cuda", generator=torch.Generator("cuda").manual_seed(3))
+    res = []
+    old = M.GEMM_PRECISION
+    M.GEMM_PRECISION = mode
+    try:
+        for dense in (False, True):
+            if dense:
+                monkeypatch.setenv("PN2_NO_POOL_DYP", "1")
+            for c_, b_, _ in layers:
+                for p_ in list(c_.parameters()) + list(b_.parameters()):
+                    p_.grad = None
+            x = x0.clone().requires_grad_(True)
+            out = chain_rows(x, layers, pool_k=pool_k)
+            out.backward(torch.randn(out.shape, device="cuda", generator=torch.Generator("cuda").manual_seed(4)))
+            res.append([x.grad.clone()] + [p_.grad.clone() for c_, b_, _ in layers for p_ in list(c_.parameters()) + list(b_.parameters())])
+    finally:
+        M.GEMM_PRECISION = old
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    assert float(res[0][0].abs().max()) > 0.0
 
 
 @pytest.mark.parametrize("pool_k", [32, 1])
