@@ -1,8 +1,8 @@
 """The PointTransformerV3 backbone with the reference's constructor, module tree and parameter names
 (Modules/PointTransformerV3/PointTransformerV3.py:261-460), so that a state dict of the reference's `backbone` loads: embedding
 (5 x 5 x 5 stem) -> five encoder stages (serialized pooling, Blocks) -> four decoder stages (serialized unpooling, Blocks).
-Built from blocks.py (which says what is this library's kernel and what is a plain library call).  INFERENCE ONLY, PARITY
-UNPINNED (see blocks.py); the repository's configuration -- enable_flash = enable_rpe = False, no PDNorm -- is what is built,
+Built from blocks.py (which says what is this library's kernel and what is a plain library call).  Inference and training,
+PARITY UNPINNED (see blocks.py); the repository's configuration -- enable_flash = enable_rpe = False, no PDNorm -- is what is built,
 the other options raise."""
 from functools import partial
 
@@ -70,8 +70,6 @@ class PointTransformerV3(PointModule):
     def forward(self, data_dict):
         """data_dict: "feat" [N, C], "grid_coord" [N, 3] (or "coord" + "grid_size"), "coord" [N, 3], "offset" or "batch" -> the
         Point of the finest stage with its new "feat" [N, dec_channels[0]] (:445-460)."""
-        if self.training:
-            raise NotImplementedError("PointTransformerV3: inference only (call .eval()); the backward passes are not built")
         point = Point(data_dict)
         point.serialization(order=self.order, shuffle_orders=self.shuffle_orders)
         point.sparsify()
@@ -108,7 +106,8 @@ class PointTransformerWithHeads(nn.Module):
     """PointTransformerV3.py:19-258 at inference: the backbone on the voxels of `coords` at `voxel_size` (several points may share a
     voxel: a duplicate voxel is represented by its lowest-index point in the neighbour tables), the semantic and the offset head on
     its 64 output features, `forward(batch, return_loss)` and the prediction-averaging `forward_hierarchical_streaming(batch,
-    return_loss=False)`.  `return_loss=True` evaluates the reference's loss on the outputs (validation); training mode raises."""
+    return_loss=False)`.  `forward(batch, return_loss=True)` is the training step's forward (loss, loss_dict): every stage is
+    differentiable (attention and submanifold-conv backward kernels of this library, torch autograd for the dense layers)."""
 
     def __init__(self, dim_feat=4, use_feats=False, voxel_size=0.02, loss_multiplier_semantic=1, loss_multiplier_offset=1,
                  enable_flash=False, optional_autocast=True, **kwargs):
@@ -162,7 +161,9 @@ class PointTransformerWithHeads(nn.Module):
         """:117-243 for return_loss=False: per-mini-batch predictions averaged over the tree (`avg[ids] += x`, the reference's
         index_put: one contribution per id and mini-batch)."""
         if return_loss:
-            raise NotImplementedError("PointTransformerWithHeads: the training pass of forward_hierarchical_streaming is not built")
+            raise NotImplementedError("PointTransformerWithHeads.forward_hierarchical_streaming(return_loss=True): the reference's own "
+                                      "code for this pass cannot run (it permutes the backbone's Point, PointTransformerV3.py:161); train "
+                                      "through forward(batch, return_loss=True)")
         n, dev = batch["cloud_length"], "cuda"
         avg_off, avg_sem = torch.zeros((n, 3), device=dev), torch.zeros((n, 2), device=dev)
         cnt_sem, cnt_off = torch.zeros((n, 1), device=dev), torch.zeros((n, 1), device=dev)

@@ -4,9 +4,9 @@ branch, :466-488, as ONE launch of csrc/ptv3_attention.hip -- the K x K score ma
 `SerializedAttention` with the reference's constructor, parameter names (`qkv`, `proj`) and `forward(point)`.
 
 The repository's configuration is the non-flash path (PointTransformerV3.py:283-286: enable_flash = enable_rpe = False,
-head width 16 in every stage); `enable_flash=True` (flash_attn's fp16 kernels) and `enable_rpe=True` raise.  Inference only
-for now: the attention backward is not built, a tensor that requires grad raises.  The two linear layers are plain library
-GEMMs (torch.nn.Linear).  Parity: the reference module cannot be imported here (spconv / torch_scatter / addict / timm at
+head width 16 in every stage); `enable_flash=True` (flash_attn's fp16 kernels) and `enable_rpe=True` raise.  Training: the
+forward then also keeps the rows' log-sum-exp and the backward is two more launches of the same file (dq; dk + dv) that rebuild
+the probabilities block by block.  The two linear layers are plain library GEMMs (torch.nn.Linear).  Parity: the reference module cannot be imported here (spconv / torch_scatter / addict / timm at
 module level), so the oracle (oracle/ptv3_attention_port.py) restates the source text: PARITY UNPINNED."""
 import ctypes
 
@@ -47,25 +47,57 @@ def get_padding_and_inverse(offset, patch_size):
     return pad, unpad, cu
 
 
-def patch_attention(qkv, order, patch_size, num_heads, scale):
-    """qkv [N, 3 C] fp32 rows ([3][H][C / H]), order [N'] int64 or None (rows of qkv behind the padded positions: the
-    reference's `qkv[order]`), N' a multiple of patch_size -> feat [N', C] = softmax((q scale) k^T) v per patch and head."""
-    _hip.require_device(qkv, order)
-    if qkv.requires_grad and torch.is_grad_enabled():
-        raise NotImplementedError("patch_attention: the backward pass is not built (inference only)")
-    qkv = _hip.f32(qkv)
-    if qkv.stride(1) != 1:
-        qkv = qkv.contiguous()
+def _attention_forward(qkv, order, K, H, scale, want_lse):
     C = qkv.shape[1] // 3
     n_rows = qkv.shape[0] if order is None else order.numel()
+    out = torch.empty(n_rows, C, dtype=torch.float32, device=qkv.device)
+    lse = torch.empty(n_rows, H, dtype=torch.float32, device=qkv.device) if want_lse else None
+    _hip.call("ptv3_attention", _hip.lib().pn2_ptv3_patch_attention_lse_f32, qkv.data_ptr(), qkv.stride(0), _hip.ptr(order), n_rows, K, H,
+              C // H, ctypes.c_float(float(scale)), out.data_ptr(), _hip.ptr(lse), _PRECISION_CODE[ATTENTION_PRECISION],
+              _hip.stream_ptr(), nbytes=16 * n_rows * C, flops=4 * n_rows * K * C)
+    return out, lse
+
+
+class _PatchAttentionFn(torch.autograd.Function):
+    """Training path of `patch_attention`: the forward keeps (qkv, order, out, lse); the backward writes the gradient of the
+    GATHERED rows and adds the rows several padded positions read (the repeated tail of a cloud's last patch) with index_add."""
+
+    @staticmethod
+    def forward(ctx, qkv, order, K, H, scale):
+        out, lse = _attention_forward(qkv, order, K, H, scale, True)
+        ctx.save_for_backward(qkv, order, out, lse)
+        ctx.cfg = (K, H, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, order, out, lse = ctx.saved_tensors
+        K, H, scale = ctx.cfg
+        dout = _hip.f32(dout).contiguous()
+        n_rows, C = out.shape
+        drows = torch.empty(n_rows, 3 * C, dtype=torch.float32, device=qkv.device)
+        _hip.call("ptv3_attention_bwd", _hip.lib().pn2_ptv3_patch_attention_bwd_f32, qkv.data_ptr(), qkv.stride(0), _hip.ptr(order), n_rows,
+                  K, H, C // H, ctypes.c_float(float(scale)), out.data_ptr(), lse.data_ptr(), dout.data_ptr(), drows.data_ptr(),
+                  _hip.stream_ptr(), nbytes=28 * n_rows * C, flops=14 * n_rows * K * C)
+        if order is None:
+            return drows, None, None, None, None
+        return torch.zeros_like(qkv).index_add_(0, order, drows), None, None, None, None
+
+
+def patch_attention(qkv, order, patch_size, num_heads, scale):
+    """qkv [N, 3 C] fp32 rows ([3][H][C / H]), order [N'] int64 or None (rows of qkv behind the padded positions: the
+    reference's `qkv[order]`), N' a multiple of patch_size -> feat [N', C] = softmax((q scale) k^T) v per patch and head.
+    Differentiable w.r.t. qkv."""
+    _hip.require_device(qkv, order)
+    qkv = _hip.f32(qkv)
+    if qkv.stride(1) != 1 or qkv.stride(0) % 4:
+        qkv = qkv.contiguous()
     if order is not None:
         order = order.to(torch.int64).contiguous()
-    out = torch.empty(n_rows, C, dtype=torch.float32, device=qkv.device)
     K, H = int(patch_size), int(num_heads)
-    _hip.call("ptv3_attention", _hip.lib().pn2_ptv3_patch_attention_f32, qkv.data_ptr(), qkv.stride(0), _hip.ptr(order), n_rows, K, H,
-              C // H, ctypes.c_float(float(scale)), out.data_ptr(), _PRECISION_CODE[ATTENTION_PRECISION], _hip.stream_ptr(),
-              nbytes=16 * n_rows * C, flops=4 * n_rows * K * C)
-    return out
+    if qkv.requires_grad and torch.is_grad_enabled():
+        return _PatchAttentionFn.apply(qkv, order, K, H, float(scale))
+    return _attention_forward(qkv, order, K, H, scale, False)[0]
 
 
 class SerializedAttention(nn.Module):

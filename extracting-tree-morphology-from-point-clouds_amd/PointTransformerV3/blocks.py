@@ -8,10 +8,10 @@ conditional positional encoding (csrc/ptv3_cpe.hip) -- are this library's kernel
 layers are plain library calls (torch), and so is the index bookkeeping of the pooling (unique / sort / segment reductions: the
 reference's torch + torch_scatter calls, torch_scatter.segment_csr spelled torch.segment_reduce).  The reference's dependencies
 (spconv, torch_scatter, addict, timm) are absent here, so `Point` is a plain dict with attribute access, a voxel set carries its
-neighbour tables instead of a spconv.SparseConvTensor, and DropPath is the identity it is at inference.
+neighbour tables instead of a spconv.SparseConvTensor.
 
-INFERENCE ONLY (no backward for the attention and the sparse convolutions); PARITY UNPINNED against the reference, whose module
-cannot be imported here -- the restatement the tests use is oracle/ptv3_model_port.py."""
+Inference and training (the attention and the sparse convolutions have backward kernels, attention.py / cpe.py; the rest is
+torch autograd); PARITY UNPINNED against the reference, whose module cannot be imported here -- the restatement the tests use is oracle/ptv3_model_port.py."""
 import math
 from collections import OrderedDict
 
@@ -159,16 +159,22 @@ class MLP(nn.Module):
 
 
 class DropPath(nn.Module):
-    """timm.layers.DropPath at inference: the identity (a training forward with a positive rate is not built)."""
+    """timm.layers.DropPath (stochastic depth, scale_by_keep=True): in training every ROW of the residual branch (the first
+    dimension is the sample dimension -- here a point, as in the reference, where the module sees `point.feat` [N, C]) is kept with
+    probability 1 - drop_prob and scaled by 1 / (1 - drop_prob); the identity at inference or with rate 0."""
 
-    def __init__(self, drop_prob=0.0):
+    def __init__(self, drop_prob=0.0, scale_by_keep=True):
         super().__init__()
-        self.drop_prob = drop_prob
+        self.drop_prob, self.scale_by_keep = drop_prob, scale_by_keep
 
     def forward(self, x):
-        if self.training and self.drop_prob > 0.0:
-            raise NotImplementedError("DropPath in training mode (stochastic depth) is not built: inference only")
-        return x
+        if not self.training or self.drop_prob == 0.0:
+            return x
+        keep = 1.0 - self.drop_prob
+        mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
+        if keep > 0.0 and self.scale_by_keep:
+            mask.div_(keep)
+        return x * mask
 
 
 class Block(PointModule):

@@ -9,8 +9,9 @@ indice_key=...)` on the voxels of `Point.sparsify`, :153-190) as two launches of
 of the reference's CPE loads.  Semantics = the operator's definition: the dense cross-correlation conv3d(padding = 1) of the
 voxel grid evaluated at the active voxels, the three grid axes in the order of `grid_coord`'s columns (spconv's D, H, W).
 spconv itself is a CUDA-only dependency that is absent here: PARITY UNPINNED against it, pinned against
-torch.nn.functional.conv3d (tests/test_ptv3_cpe.py).  Inference only: no backward is built, a tensor that requires grad
-raises."""
+torch.nn.functional.conv3d (tests/test_ptv3_cpe.py).  Training: the input gradient is the same kernel on the mirrored stencil
+(distinct voxels: j(i, d) = j' <=> j(j', -d) = i, which is also what spconv's indice pairs assume), the weight gradient a gathered
+split-K contraction (`pn2_ptv3_subm_wgrad_f32`), both fp32."""
 import math
 
 import torch
@@ -88,10 +89,8 @@ class SubMConv3d(nn.Module):
             self._packed16 = (key, w.to(torch.bfloat16).contiguous())
         return self._packed16[1]
 
-    def forward(self, feat, nbr):
+    def _prepare(self, feat, nbr):
         _hip.require_device(feat, nbr)
-        if torch.is_grad_enabled() and feat.requires_grad:
-            raise NotImplementedError("SubMConv3d: the backward pass is not built (inference only)")
         feat = _hip.f32(feat)
         cin = self._cin_padded
         if cin != self.in_channels:
@@ -101,11 +100,66 @@ class SubMConv3d(nn.Module):
         N = feat.shape[0]
         if nbr.shape != (N, self.kernel_size ** 3):
             raise RuntimeError(f"SubMConv3d: neighbour table {tuple(nbr.shape)} does not fit {N} voxels, kernel_size {self.kernel_size}")
-        out = torch.empty(N, self.out_channels, dtype=torch.float32, device=feat.device)
+        return feat
+
+    def forward(self, feat, nbr):
+        feat = self._prepare(feat, nbr)
+        if torch.is_grad_enabled() and (feat.requires_grad or self.weight.requires_grad):
+            return _SubMConvFn.apply(feat, nbr, self.weight, self.bias, self)
         w = self._offset_major()
-        w16 = self._offset_major_bf16() if (CONV_PRECISION == "bf16" and self.kernel_size == 3 and cin >= 64) else None
+        w16 = self._offset_major_bf16() if (CONV_PRECISION == "bf16" and self.kernel_size == 3 and self._cin_padded >= 64) else None
         b = None if self.bias is None else self.bias.detach().float().contiguous()
-        _hip.call("ptv3_subm_conv", _hip.lib().pn2_ptv3_subm_conv_f32, feat.data_ptr(), feat.stride(0), nbr.data_ptr(), self.kernel_size,
-                  w.data_ptr(), _hip.ptr(w16), _hip.ptr(b), N, cin, self.out_channels, out.data_ptr(), out.stride(0), _hip.stream_ptr(),
-                  nbytes=4 * N * (nbr.shape[1] + cin + self.out_channels), flops=2 * nbr.shape[1] * N * cin * self.out_channels)
-        return out
+        return _conv(feat, nbr, self.kernel_size, w, w16, b, self.out_channels)
+
+
+def _conv(feat, nbr, kernel_size, w, w16, bias, cout):
+    """One launch of pn2_ptv3_subm_conv_f32: feat [N, C_in] (C_in = w.shape[1]), w [k^3, C_in, cout] -> [N, cout]."""
+    N, cin = feat.shape[0], w.shape[1]
+    out = torch.empty(N, cout, dtype=torch.float32, device=feat.device)
+    _hip.call("ptv3_subm_conv", _hip.lib().pn2_ptv3_subm_conv_f32, feat.data_ptr(), feat.stride(0), nbr.data_ptr(), kernel_size,
+              w.data_ptr(), _hip.ptr(w16), _hip.ptr(bias), N, cin, cout, out.data_ptr(), out.stride(0), _hip.stream_ptr(),
+              nbytes=4 * N * (nbr.shape[1] + cin + cout), flops=2 * nbr.shape[1] * N * cin * cout)
+    return out
+
+
+class _SubMConvFn(torch.autograd.Function):
+    """out = SubMConv3d(feat) under autograd.  feat arrives padded to the kernel's input width; `weight` / `bias` are the module's
+    parameters in spconv's layout."""
+
+    @staticmethod
+    def forward(ctx, feat, nbr, weight, bias, mod):
+        w = mod._offset_major()
+        w16 = mod._offset_major_bf16() if (CONV_PRECISION == "bf16" and mod.kernel_size == 3 and mod._cin_padded >= 64) else None
+        b = None if bias is None else bias.detach().float().contiguous()
+        ctx.save_for_backward(feat, nbr, w)
+        ctx.mod = mod
+        ctx.has_bias = bias is not None
+        return _conv(feat, nbr, mod.kernel_size, w, w16, b, mod.out_channels)
+
+    @staticmethod
+    def backward(ctx, dout):
+        feat, nbr, w = ctx.saved_tensors
+        mod = ctx.mod
+        k, cin, cout = mod.kernel_size, mod._cin_padded, mod.out_channels
+        dout = _hip.f32(dout)
+        if dout.stride(1) != 1 or dout.stride(0) % 4:
+            dout = dout.contiguous()
+        N = feat.shape[0]
+        dfeat = dweight = dbias = None
+        if ctx.needs_input_grad[0]:
+            if cin % 32 or cout % 16:
+                raise NotImplementedError("SubMConv3d backward: the input gradient needs C_in a multiple of 32 (the CPE layers; the "
+                                          "stem's raw features take no gradient)")
+            dfeat = _conv(dout, nbr, k, w.flip(0).transpose(1, 2).contiguous(), None, None, cin)   # W'[d][co][ci] = W[-d][ci][co]
+        if ctx.needs_input_grad[2]:
+            lib = _hip.lib()
+            dw = torch.empty(k ** 3, cin, cout, dtype=torch.float32, device=feat.device)
+            ws = torch.empty(lib.pn2_ptv3_subm_wgrad_workspace_bytes(N, k, cin, cout), dtype=torch.uint8, device=feat.device)
+            _hip.call("ptv3_subm_wgrad", lib.pn2_ptv3_subm_wgrad_f32, feat.data_ptr(), feat.stride(0), nbr.data_ptr(), k, dout.data_ptr(),
+                      dout.stride(0), N, cin, cout, dw.data_ptr(), ws.data_ptr(), ws.numel(), _hip.stream_ptr(),
+                      nbytes=4 * N * k ** 3 * (1 + cout), flops=2 * k ** 3 * N * cin * cout)
+            # [k^3][C_in padded][C_out] -> spconv's [C_out, k, k, k, C_in]
+            dweight = dw[:, :mod.in_channels, :].reshape(k, k, k, mod.in_channels, cout).permute(4, 0, 1, 2, 3).contiguous()
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            dbias = dout.sum(0)
+        return dfeat, None, dweight, dbias, None

@@ -118,6 +118,10 @@ SIGNATURES = {
     "pn2_ptv3_subm_conv_f32": (_int, [_vp, _i64, _vp, _int, _vp, _vp, _vp, _int, _int, _int, _vp, _i64, _vp]),
     "pn2_ptv3_pad_unpad_i64": (_int, [_vp, _vp, _vp, _int, _int, _i64, _vp, _vp, _vp, _vp]),
     "pn2_ptv3_patch_attention_f32": (_int, [_vp, _i64, _vp, _i64, _int, _int, _int, _f32, _vp, _int, _vp]),
+    "pn2_ptv3_patch_attention_lse_f32": (_int, [_vp, _i64, _vp, _i64, _int, _int, _int, _f32, _vp, _vp, _int, _vp]),
+    "pn2_ptv3_patch_attention_bwd_f32": (_int, [_vp, _i64, _vp, _i64, _int, _int, _int, _f32, _vp, _vp, _vp, _vp, _vp]),
+    "pn2_ptv3_subm_wgrad_workspace_bytes": (_sz, [_int, _int, _int, _int]),
+    "pn2_ptv3_subm_wgrad_f32": (_int, [_vp, _i64, _vp, _int, _vp, _i64, _int, _int, _int, _vp, _vp, _sz, _vp]),
     "pn2_prof_enable": (None, [_int]),
     "pn2_prof_collect": (_int, [ctypes.c_char_p, _sz, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong),
                                 ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), _int]),
@@ -155,7 +159,7 @@ SIGNATURES = {
 }
 
 _lib = None
-ABI_VERSION = 5                      # PN2_ABI_VERSION of include/pn2_hip.h
+ABI_VERSION = 6                      # PN2_ABI_VERSION of include/pn2_hip.h
 CHAIN_ACCUMULATE_DX = 0x100          # PN2_CHAIN_ACCUMULATE_DX
 CHAIN_LAZY_OUT = 0x400               # PN2_CHAIN_LAZY_OUT
 CHAIN_ZERO_LEAD = 0x800              # PN2_CHAIN_ZERO_LEAD

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void ptv3_pad_kernel(const long long* __restri
 template <bool BF16>
 __global__ __launch_bounds__(AT, 1) void ptv3_attention_kernel(const float* __restrict__ qkv, long long ld,
                                                                const long long* __restrict__ order, int K, int H, float scale,
-                                                               float* __restrict__ out) {
+                                                               float* __restrict__ out, float* __restrict__ lse) {
     __shared__ float sK[AKMAX * ALD], sV[AKMAX * ALD];
     const int patch = blockIdx.x / H, h = blockIdx.x - patch * H;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -182,6 +182,8 @@ __global__ __launch_bounds__(AT, 1) void ptv3_attention_kernel(const float* __re
     for (int j = 0; j < 4; ++j) {
         lsum[j] += __shfl_xor(lsum[j], 16, 64);
         lsum[j] += __shfl_xor(lsum[j], 32, 64);
+        // (training: the row's log-sum-exp, from which the backward kernels rebuild the probabilities)
+        if (lse && g == 0 && qbase + 16 * j + l16 < K) lse[(row0 + qbase + 16 * j + l16) * H + h] = m[j] + __logf(lsum[j]);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float l = __shfl(lsum[j], 4 * g + i, 64);
@@ -189,6 +191,155 @@ __global__ __launch_bounds__(AT, 1) void ptv3_attention_kernel(const float* __re
             if (q < K) out[(row0 + q) * C + h * AD + l16] = o[j][i] / l;
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Backward of the patch attention (training).  With qs = q * scale, S = qs K^T, P = softmax(S) = exp(S - lse), O = P V:
+//     delta_i = dO_i . O_i      dP = dO V^T      dS = P o (dP - delta)      dqs = dS K      dK = dS^T qs      dV = P^T dO
+// Two launches, one workgroup per (patch, head) each, built like the forward kernel (one operand set staged in LDS once, the
+// other in the owning wavefront's registers, probabilities straight from one MFMA's result registers into the next one's
+// operand registers) -- the K x K matrices are rebuilt block by block, never written:
+//   ROLE 0  a wavefront owns 64 QUERIES (qs, dO, lse, delta in registers), keys / values stream from LDS; S^T and dP^T blocks
+//           (key rows, query columns) -> dS^T -> dqs += dS K
+//   ROLE 1  a wavefront owns 64 KEYS (K, V in registers), qs / dO / lse / delta stream from LDS; S and dP blocks (query rows,
+//           key columns) -> dV += P^T dO, dK += dS^T qs
+// Exact fp32 MFMA (v_mfma_f32_16x16x4_f32) in both precisions of the forward.  The gradients go to the PADDED positions
+// (dg [n_rows][3 C], rows like qkv's): a row of qkv that several padded positions read (the repeated tail of a cloud's last
+// patch) collects them in the caller (index_add over `order`).
+template <int ROLE>
+__global__ __launch_bounds__(AT, 1) void ptv3_attention_bwd_kernel(const float* __restrict__ qkv, long long ld,
+                                                                   const long long* __restrict__ order, int K, int H, float scale,
+                                                                   const float* __restrict__ out, const float* __restrict__ lse,
+                                                                   const float* __restrict__ dout, float* __restrict__ dg) {
+    __shared__ float sA[AKMAX * ALD], sB[AKMAX * ALD];   // ROLE 0: K, V rows; ROLE 1: qs, dO rows
+    __shared__ float sL[AKMAX], sD[AKMAX];               // ROLE 1: lse, delta of every query
+    const int patch = blockIdx.x / H, h = blockIdx.x - patch * H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int C = H * AD;
+    const long long row0 = (long long)patch * K;
+    const int KP = (K + 15) & ~15;
+    for (int e = tid; e < KP * 4; e += AT) {
+        const int r = e >> 2, c4 = (e & 3) * 4;
+        float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f), b4 = a4;
+        float part = 0.0f;
+        if (r < K) {
+            const long long src = order ? order[row0 + r] : row0 + r;
+            const float* p = qkv + src * ld + h * AD + c4;
+            if (ROLE == 0) {
+                a4 = *(const float4*)(p + C);
+                b4 = *(const float4*)(p + 2 * C);
+            } else {
+                a4 = *(const float4*)p;
+                a4.x *= scale, a4.y *= scale, a4.z *= scale, a4.w *= scale;
+                b4 = *(const float4*)(dout + (row0 + r) * C + h * AD + c4);
+                const float4 o4 = *(const float4*)(out + (row0 + r) * C + h * AD + c4);
+                part = (b4.x * o4.x + b4.y * o4.y) + (b4.z * o4.z + b4.w * o4.w);
+            }
+        }
+        float* da = sA + r * ALD + c4;
+        float* db = sB + r * ALD + c4;
+        da[0] = a4.x, da[1] = a4.y, da[2] = a4.z, da[3] = a4.w;
+        db[0] = b4.x, db[1] = b4.y, db[2] = b4.z, db[3] = b4.w;
+        if (ROLE == 1) {   // the row's four quarters sit in four neighbouring lanes (KP * 4 is a multiple of 64: whole wavefronts)
+            part += __shfl_xor(part, 1, 64);
+            part += __shfl_xor(part, 2, 64);
+            if ((e & 3) == 0) {
+                sD[r] = part;
+                sL[r] = r < K ? lse[(row0 + r) * H + h] : __builtin_inff();   // rows beyond the patch: p = exp(-inf) = 0
+            }
+        }
+    }
+    // ---- the rows this wavefront owns: 4 blocks of 16, B-operand layout (row = lane % 16, d = 4 * step + lane / 16)
+    const int l16 = lane & 15, g = lane >> 4;
+    float uf[4][4], wf[4][4];   // ROLE 0: qs, dO;  ROLE 1: K, V
+    float lq[4], dq_[4];        // ROLE 0: lse and delta of query lane % 16 of block j
+    const int base = wave * 64;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = base + 16 * j + l16;
+        const bool in = r < K;
+        const long long src = in ? (order ? order[row0 + r] : row0 + r) : 0;
+        const float* p = qkv + src * ld + h * AD;
+        float part = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (ROLE == 0) {
+                uf[j][s] = in ? p[4 * s + g] * scale : 0.0f;
+                wf[j][s] = in ? dout[(row0 + r) * C + h * AD + 4 * s + g] : 0.0f;
+                part += in ? wf[j][s] * out[(row0 + r) * C + h * AD + 4 * s + g] : 0.0f;
+            } else {
+                uf[j][s] = in ? p[C + 4 * s + g] : 0.0f;
+                wf[j][s] = in ? p[2 * C + 4 * s + g] : 0.0f;
+            }
+        }
+        if (ROLE == 0) {
+            part += __shfl_xor(part, 16, 64);
+            part += __shfl_xor(part, 32, 64);
+            dq_[j] = part;
+            lq[j] = in ? lse[(row0 + r) * H + h] : __builtin_inff();
+        }
+    }
+    __syncthreads();
+    if (base >= K) return;   // (a short patch: this wavefront owns nothing; no barrier follows)
+    const int nb = KP / 16;
+    f32x4 acc0[4], acc1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc0[j] = f32x4{0.f, 0.f, 0.f, 0.f}, acc1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < nb; ++b) {
+        // streamed block: A-operand layout (row = lane % 16, d = 4 * step + lane / 16) and contraction layout (row = 4 g + i, d = lane % 16)
+        float ar[4], br[4], ac[4], bc[4], ls[4], de[4];
+        const float* pa = sA + (16 * b + l16) * ALD;
+        const float* pb = sB + (16 * b + l16) * ALD;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) ar[s] = pa[4 * s + g], br[s] = pb[4 * s + g];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ac[i] = sA[(16 * b + 4 * g + i) * ALD + l16];
+            bc[i] = sB[(16 * b + 4 * g + i) * ALD + l16];
+            if (ROLE == 1) ls[i] = sL[16 * b + 4 * g + i], de[i] = sD[16 * b + 4 * g + i];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // lane holds element (streamed row 4 g + i, owned row lane % 16) of the score block and of dP's
+            f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                sc = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[s], uf[j][s], sc, 0, 0, 0);                       // K qs^T | qs K^T
+                dp = __builtin_amdgcn_mfma_f32_16x16x4f32(ROLE == 0 ? br[s] : br[s], wf[j][s], dp, 0, 0, 0);   // V dO^T | dO V^T
+            }
+            float pr[4], ds[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool live = ROLE == 0 ? (16 * b + 4 * g + i < K) : true;   // (ROLE 1: rows beyond the patch carry lse = inf)
+                pr[i] = live ? __expf(sc[i] - (ROLE == 0 ? lq[j] : ls[i])) : 0.0f;
+                ds[i] = pr[i] * (dp[i] - (ROLE == 0 ? dq_[j] : de[i]));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (ROLE == 0) {
+                    acc0[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ds[i], ac[i], acc0[j], 0, 0, 0);   // dqs += dS K
+                } else {
+                    acc0[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ds[i], ac[i], acc0[j], 0, 0, 0);   // dK += dS^T qs
+                    acc1[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(pr[i], bc[i], acc1[j], 0, 0, 0);   // dV += P^T dO
+                }
+            }
+        }
+    }
+    // ---- store: acc[j][i] = gradient of owned row 4 g + i of block j, column d = lane % 16
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = base + 16 * j + 4 * g + i;
+            if (r >= K) continue;
+            float* d = dg + (row0 + r) * 3 * C + h * AD + l16;
+            if (ROLE == 0) {
+                d[0] = acc0[j][i] * scale;
+            } else {
+                d[C] = acc0[j][i];
+                d[2 * C] = acc1[j][i];
+            }
+        }
 }
 
 }  // namespace
@@ -205,24 +356,51 @@ extern "C" int pn2_ptv3_pad_unpad_i64(const int64_t* off, const int64_t* offpad,
     return 0;
 }
 
-extern "C" int pn2_ptv3_patch_attention_f32(const float* qkv, int64_t ld, const int64_t* order, int64_t n_rows, int patch_size,
-                                            int heads, int head_dim, float scale, float* out, int precision, void* stream) {
-    if (!qkv || !out || n_rows <= 0 || patch_size <= 0 || heads <= 0) return PN2_E_BADARG;
-    if (head_dim != AD || patch_size > AKMAX || n_rows % patch_size) return PN2_E_BADARG;   // the repository's configuration
-    if (ld % 4 || ((uintptr_t)qkv & 15) || ld < 3ll * heads * head_dim) return PN2_E_BADARG;
+static int attention_args_ok(const float* qkv, int64_t ld, int64_t n_rows, int patch_size, int heads, int head_dim) {
+    if (!qkv || n_rows <= 0 || patch_size <= 0 || heads <= 0) return 0;
+    if (head_dim != AD || patch_size > AKMAX || n_rows % patch_size) return 0;   // the repository's configuration
+    if (ld % 4 || ((uintptr_t)qkv & 15) || ld < 3ll * heads * head_dim) return 0;
+    return (n_rows / patch_size) * heads <= 0x7FFFFFFFll;
+}
+
+extern "C" int pn2_ptv3_patch_attention_lse_f32(const float* qkv, int64_t ld, const int64_t* order, int64_t n_rows, int patch_size,
+                                                int heads, int head_dim, float scale, float* out, float* lse, int precision,
+                                                void* stream) {
+    if (!out || !attention_args_ok(qkv, ld, n_rows, patch_size, heads, head_dim)) return PN2_E_BADARG;
     if (precision != PN2_PRECISION_F32 && precision != PN2_PRECISION_BF16) return PN2_E_BADARG;
     const long long patches = n_rows / patch_size;
-    if (patches * heads > 0x7FFFFFFFll) return PN2_E_BADARG;
     const double kk = (double)patch_size * patch_size;
     const double flops = (double)patches * heads * 4.0 * kk * AD;                       // Q K^T and P V once each
     const double bytes = 4.0 * (double)n_rows * heads * AD * 4.0;                        // q, k, v read, out written
     const dim3 grid((unsigned)(patches * heads)), block(AT);
     if (precision == PN2_PRECISION_BF16)
         PN2_LAUNCH("ptv3_attention_bf16", bytes, flops, (ptv3_attention_kernel<true>), grid, block, (hipStream_t)stream, qkv, (long long)ld,
-                   (const long long*)order, patch_size, heads, scale, out);
+                   (const long long*)order, patch_size, heads, scale, out, lse);
     else
         PN2_LAUNCH("ptv3_attention", bytes, flops, (ptv3_attention_kernel<false>), grid, block, (hipStream_t)stream, qkv, (long long)ld,
-                   (const long long*)order, patch_size, heads, scale, out);
+                   (const long long*)order, patch_size, heads, scale, out, lse);
+    PN2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int pn2_ptv3_patch_attention_f32(const float* qkv, int64_t ld, const int64_t* order, int64_t n_rows, int patch_size,
+                                            int heads, int head_dim, float scale, float* out, int precision, void* stream) {
+    return pn2_ptv3_patch_attention_lse_f32(qkv, ld, order, n_rows, patch_size, heads, head_dim, scale, out, nullptr, precision, stream);
+}
+
+extern "C" int pn2_ptv3_patch_attention_bwd_f32(const float* qkv, int64_t ld, const int64_t* order, int64_t n_rows, int patch_size,
+                                                int heads, int head_dim, float scale, const float* out, const float* lse,
+                                                const float* dout, float* dqkv_rows, void* stream) {
+    if (!out || !lse || !dout || !dqkv_rows || !attention_args_ok(qkv, ld, n_rows, patch_size, heads, head_dim)) return PN2_E_BADARG;
+    if (((uintptr_t)out & 15) || ((uintptr_t)dout & 15)) return PN2_E_BADARG;
+    const long long patches = n_rows / patch_size;
+    const double kk = (double)patch_size * patch_size;
+    const double bytes = 4.0 * (double)n_rows * heads * AD * 6.0;
+    const dim3 grid((unsigned)(patches * heads)), block(AT);
+    PN2_LAUNCH("ptv3_attention_bwd_q", bytes, (double)patches * heads * 6.0 * kk * AD, (ptv3_attention_bwd_kernel<0>), grid, block,
+               (hipStream_t)stream, qkv, (long long)ld, (const long long*)order, patch_size, heads, scale, out, lse, dout, dqkv_rows);
+    PN2_LAUNCH("ptv3_attention_bwd_kv", bytes, (double)patches * heads * 8.0 * kk * AD, (ptv3_attention_bwd_kernel<1>), grid, block,
+               (hipStream_t)stream, qkv, (long long)ld, (const long long*)order, patch_size, heads, scale, out, lse, dout, dqkv_rows);
     PN2_LAUNCH_CHECK();
     return 0;
 }

@@ -394,6 +394,80 @@ inline size_t table_slots(int N) {
     return t;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Training: the weight gradient  dW[o][ci][co] = sum_i X[nbr[i][o]][ci] * dY[i][co]  (offset-major like the forward's packed
+// weights).  One workgroup per (offset, 64 x 64 tile of (ci, co), row range): 32 rows per step -- the gathered X rows (absent
+// neighbour: zeros) and the dY rows go to LDS as [row][channel], four wavefronts own 32 x 32 each (v_mfma_f32_32x32x2_f32, the
+// contraction runs over the rows) -- a step none of whose rows has the neighbour is skipped.  Row ranges leave slabs that a
+// second launch sums in fixed order (deterministic, like the chains' split-K weight gradients).
+// The input gradient needs no kernel of its own: nbr[i][o] = j <=> nbr[j][noff - 1 - o] = i for distinct voxels, so
+// dX = subm_conv(dY, nbr, W') with W'[o][co][ci] = W[noff - 1 - o][ci][co] (PointTransformerV3/cpe.py).
+constexpr int WGK = 32, WGT = 64, WGLD = WGT + 4;
+constexpr int WG_SPLIT_ROWS = 4096, WG_MAX_SPLITS = 64;
+inline int wgrad_splits(int N) {
+    const int n = pn2::ceil_div(N, WG_SPLIT_ROWS);
+    return n < 1 ? 1 : (n > WG_MAX_SPLITS ? WG_MAX_SPLITS : n);
+}
+__global__ __launch_bounds__(256) void subm_wgrad_kernel(const float* __restrict__ feat, long long ldf, const int* __restrict__ nbr,
+                                                         int noff, const float* __restrict__ dout, long long ldo, int N, int Cin,
+                                                         int Cout, int rows_per_split, float* __restrict__ slab) {
+    __shared__ float sX[WGK * WGLD], sY[WGK * WGLD];
+    __shared__ int sIdx[WGK];
+    const int tco_n = (Cout + WGT - 1) / WGT;
+    const int o = blockIdx.x % noff, tile = blockIdx.x / noff;
+    const int ci0 = (tile / tco_n) * WGT, co0 = (tile % tco_n) * WGT;
+    const int split = blockIdx.y;
+    const int r_begin = split * rows_per_split, r_end = min(N, r_begin + rows_per_split);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    using f32x16 = __attribute__((ext_vector_type(16))) float;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int r0 = r_begin; r0 < r_end; r0 += WGK) {
+        int mine = -1;
+        if (tid < WGK) {
+            const int i = r0 + tid;
+            mine = i < r_end ? nbr[(long long)i * noff + o] : -1;
+            sIdx[tid] = mine;
+        }
+        if (!__syncthreads_or(mine >= 0)) continue;   // (also the barrier between the previous step's reads and this one's writes)
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int rr = (tid >> 4) + 16 * pass, c4 = (tid & 15) * 4;
+            const int j = sIdx[rr];
+            float4 x4 = make_float4(0.f, 0.f, 0.f, 0.f), y4 = x4;
+            if (j >= 0) {   // (a row without the neighbour contributes nothing: its dY may stay zero too)
+                if (ci0 + c4 < Cin) x4 = *(const float4*)(feat + (long long)j * ldf + ci0 + c4);
+                if (co0 + c4 < Cout) y4 = *(const float4*)(dout + (long long)(r0 + rr) * ldo + co0 + c4);
+            }
+            *(float4*)(sX + rr * WGLD + c4) = x4;
+            *(float4*)(sY + rr * WGLD + c4) = y4;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < WGK; k += 2) {
+            const float a = sX[(k + (lane >> 5)) * WGLD + 32 * wm + (lane & 31)];
+            const float b = sY[(k + (lane >> 5)) * WGLD + 32 * wn + (lane & 31)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+    }
+    float* dst = slab + ((long long)split * noff + o) * Cin * Cout;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ci = ci0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), co = co0 + 32 * wn + (lane & 31);
+        if (ci < Cin && co < Cout) dst[(long long)ci * Cout + co] = acc[r];
+    }
+}
+__global__ __launch_bounds__(256) void subm_wgrad_reduce_kernel(const float* __restrict__ slab, int nsplit, long long mn,
+                                                                float* __restrict__ dw) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < mn; e += (long long)gridDim.x * 256) {
+        float sum = 0.0f;
+        for (int sidx = 0; sidx < nsplit; ++sidx) sum += slab[(long long)sidx * mn + e];
+        dw[e] = sum;
+    }
+}
+
 }  // namespace
 
 extern "C" size_t pn2_ptv3_subm_workspace_bytes(int N) {
@@ -473,6 +547,34 @@ extern "C" int pn2_ptv3_subm_conv_f32(const float* feat, int64_t ldf, const int3
     else
         PN2_LAUNCH("ptv3_subm_conv", bytes, flops, (subm_conv_kernel<32>), grid, dim3(256), s, feat, (long long)ldf, nbr, weight, bias, N,
                    Cin, Cout, out, (long long)ldo, noff);
+    PN2_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" size_t pn2_ptv3_subm_wgrad_workspace_bytes(int N, int kernel_size, int Cin, int Cout) {
+    if (N <= 0 || Cin <= 0 || Cout <= 0 || (kernel_size != 3 && kernel_size != 5)) return 0;
+    return (size_t)wgrad_splits(N) * kernel_size * kernel_size * kernel_size * Cin * Cout * sizeof(float);
+}
+
+extern "C" int pn2_ptv3_subm_wgrad_f32(const float* feat, int64_t ldf, const int32_t* nbr, int kernel_size, const float* dout,
+                                       int64_t ldo, int N, int Cin, int Cout, float* dweight, void* workspace,
+                                       size_t workspace_bytes, void* stream) {
+    if (!feat || !nbr || !dout || !dweight || N <= 0 || Cin <= 0 || Cout <= 0 || Cin % 4 || Cout % 4 || ldf % 4 || ldo % 4 ||
+        ldf < Cin || ldo < Cout || ((uintptr_t)feat & 15) || ((uintptr_t)dout & 15) || (kernel_size != 3 && kernel_size != 5))
+        return PN2_E_BADARG;
+    if (!workspace || workspace_bytes < pn2_ptv3_subm_wgrad_workspace_bytes(N, kernel_size, Cin, Cout)) return PN2_E_WORKSPACE;
+    const int noff = kernel_size * kernel_size * kernel_size;
+    const int nsplit = wgrad_splits(N);
+    const int rps = pn2::ceil_div(pn2::ceil_div(N, nsplit), WGK) * WGK;
+    hipStream_t s = (hipStream_t)stream;
+    const long long mn = (long long)noff * Cin * Cout;
+    const dim3 grid((unsigned)(noff * pn2::ceil_div(Cin, WGT) * pn2::ceil_div(Cout, WGT)), (unsigned)nsplit);
+    PN2_LAUNCH("ptv3_subm_wgrad", 4.0 * N * noff * (1.0 + Cout) + 4.0 * nsplit * mn, 2.0 * noff * N * (double)Cin * Cout, subm_wgrad_kernel,
+               grid, dim3(256), s, feat, (long long)ldf, nbr, noff, dout, (long long)ldo, N, Cin, Cout, rps, (float*)workspace);
+    long long blocks = (mn + 255) / 256;
+    blocks = blocks > 4096 ? 4096 : blocks;
+    PN2_LAUNCH("ptv3_subm_wgrad_reduce", 4.0 * (nsplit + 1) * mn, 0, subm_wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), s,
+               (const float*)workspace, nsplit, mn, dweight);
     PN2_LAUNCH_CHECK();
     return 0;
 }

@@ -31,7 +31,7 @@ extern "C" {
 #define PN2_E_BADARG (-1)   /* null pointer / non-positive size / unsupported size */
 #define PN2_E_WORKSPACE (-2) /* workspace too small */
 
-#define PN2_ABI_VERSION 5
+#define PN2_ABI_VERSION 6
 
 /* Bits of the caller-owned sticky STATUS word (a device int32 the caller zeroes once and reads at a synchronisation
  * point it has anyway, e.g. the loss read-back; the Python mirror: ops.check_status()).  A kernel ORs a bit in when it
@@ -504,6 +504,18 @@ int pn2_ptv3_pad_unpad_i64(const int64_t *off, const int64_t *offpad, const int6
                            int64_t *pad, int64_t *unpad, int32_t *cu_seqlens, void *stream);
 int pn2_ptv3_patch_attention_f32(const float *qkv, int64_t ld, const int64_t *order, int64_t n_rows, int patch_size, int heads,
                                  int head_dim, float scale, float *out, int precision, void *stream);
+/* Training (blocks.py:457-488 under autograd).
+ * pn2_ptv3_patch_attention_lse_f32 -- the forward above that also stores lse [n_rows][heads] = log sum_k exp(s_k) of every
+ *   (padded position, head): what the backward rebuilds the probabilities from (lse NULL: exactly the call above).
+ * pn2_ptv3_patch_attention_bwd_f32 -- out, lse: what that forward returned; dout [n_rows][heads * head_dim] -> dqkv_rows
+ *   [n_rows][3 * heads * head_dim] = the gradient w.r.t. the GATHERED rows qkv[order] (every element written).  A row of qkv
+ *   read by several padded positions collects them in the caller (index_add over `order`).  Two launches (dq; dk + dv), one
+ *   workgroup per (patch, head), exact fp32 MFMA, the K x K matrices rebuilt block by block and never written. */
+int pn2_ptv3_patch_attention_lse_f32(const float *qkv, int64_t ld, const int64_t *order, int64_t n_rows, int patch_size, int heads,
+                                     int head_dim, float scale, float *out, float *lse, int precision, void *stream);
+int pn2_ptv3_patch_attention_bwd_f32(const float *qkv, int64_t ld, const int64_t *order, int64_t n_rows, int patch_size, int heads,
+                                     int head_dim, float scale, const float *out, const float *lse, const float *dout,
+                                     float *dqkv_rows, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Closest-cylinder projection       replaces Modules/Projection.py:19-114 (closest_cylinder_cuda_batch; duplicated at
@@ -582,7 +594,7 @@ int pn2_serialize_decode_i64(const int64_t *codes, long long N, int depth, int o
  *   workspace: pn2_ptv3_subm_workspace_bytes(N) (the hash table; contents irrelevant on entry).
  * pn2_ptv3_subm_conv_f32        feat [N][C_in] (row stride ldf, a multiple of 4), weight [27][C_in][C_out] (offset-major: the
  *   mirror permutes spconv's [C_out][3][3][3][C_in] parameter), bias [C_out] or NULL -> out [N][C_out] (row stride ldo).
- *   C_in a multiple of 16, C_out of 32.  fp32 (v_mfma_f32_32x32x2_f32).  Forward only.
+ *   C_in a multiple of 16, C_out of 32.  fp32 (v_mfma_f32_32x32x2_f32).
  * kernel_size 3 (the CPE: 27 offsets) or 5 (the stem of Embedding, blocks.py:783-791: 125 offsets, index
  *   (dx + 2) * 25 + (dy + 2) * 5 + (dz + 2); nbr [N][125], weight [125][C_in][C_out]); a C_in that is not a multiple of 16 (the stem's
  *   input features) is zero-padded by the caller.
@@ -595,6 +607,17 @@ int pn2_ptv3_subm_neighbors_i32(const int64_t *batch, const int32_t *grid_coord,
 int pn2_ptv3_subm_conv_f32(const float *feat, int64_t ldf, const int32_t *nbr, int kernel_size, const float *weight,
                            const void *weight_bf16, const float *bias, int N, int Cin, int Cout, float *out, int64_t ldo,
                            void *stream);
+/* Training (spconv's SubMConv3d backward).
+ * pn2_ptv3_subm_wgrad_f32   dweight [k^3][C_in][C_out] (offset-major, like `weight` above; every element written)
+ *       = sum_i feat[j(i, d)]^T dout[i]: a gathered split-K contraction on v_mfma_f32_32x32x2_f32 whose row ranges leave slabs in
+ *   the workspace (pn2_ptv3_subm_wgrad_workspace_bytes) that a second launch sums in fixed order (deterministic).  C_in, C_out
+ *   multiples of 4.
+ * The input gradient is the forward kernel on the mirrored stencil: for distinct voxels j(i, d) = j' <=> j(j', -d) = i, so
+ *   dfeat = pn2_ptv3_subm_conv_f32(dout, nbr, W') with W'[d][co][ci] = W[-d][ci][co] (the mirror builds W'); the bias
+ *   gradient is a column sum. */
+size_t pn2_ptv3_subm_wgrad_workspace_bytes(int N, int kernel_size, int Cin, int Cout);
+int pn2_ptv3_subm_wgrad_f32(const float *feat, int64_t ldf, const int32_t *nbr, int kernel_size, const float *dout, int64_t ldo,
+                            int N, int Cin, int Cout, float *dweight, void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -18,6 +18,7 @@ F64 = torch.float64
 
 
 def _t(sd, k):
+    """Every parameter / buffer read goes through here (tests/test_ptv3_train.py swaps it for float64 leaves to differentiate)."""
     return sd[k].detach().cpu().to(F64)
 
 
@@ -52,15 +53,15 @@ def _block(sd, p, pt, num_heads, patch_size, order_index, parts=None):
     """Block.forward :598-623 (pre-norm)."""
     feat = pt["feat"]
     nbr = pt["nbr"].setdefault(3, C.subm_neighbors(pt["batch"], pt["grid"], 3))
-    x = C.subm_conv(feat, nbr, sd[p + ".cpe.0.weight"].detach().cpu().numpy(), sd[p + ".cpe.0.bias"].detach().cpu().numpy())
+    x = C.subm_conv(feat, nbr, _t(sd, p + ".cpe.0.weight"), _t(sd, p + ".cpe.0.bias"))
     x = _layernorm(sd, p + ".cpe.2", _linear(sd, p + ".cpe.1", x))
     if parts is not None:
         parts["cpe"] = x.clone()
     feat = feat + x
     y = _layernorm(sd, p + ".norm1.0", feat)
     y = A.serialized_attention(y, pt["offset"], pt["order"][order_index], pt["inverse"][order_index],
-                               sd[p + ".attn.qkv.weight"].detach().cpu(), sd[p + ".attn.qkv.bias"].detach().cpu(),
-                               sd[p + ".attn.proj.weight"].detach().cpu(), sd[p + ".attn.proj.bias"].detach().cpu(), num_heads, patch_size)
+                               _t(sd, p + ".attn.qkv.weight"), _t(sd, p + ".attn.qkv.bias"),
+                               _t(sd, p + ".attn.proj.weight"), _t(sd, p + ".attn.proj.bias"), num_heads, patch_size)
     if parts is not None:
         parts["attn"] = y.clone()
     feat = feat + y
@@ -115,7 +116,7 @@ def backbone_forward(sd, cfg, feat, coord, grid_coord, batch, trace=None):
           "offset": np.cumsum(np.bincount(batch)), "code": code, "order": order, "inverse": inverse, "depth": depth, "nbr": {}}
     # Embedding :770-800
     nbr5 = C.subm_neighbors(batch, grid, 5)
-    x = C.subm_conv(pt["feat"], nbr5, sd["embedding.stem.conv.weight"].detach().cpu().numpy(), None)
+    x = C.subm_conv(pt["feat"], nbr5, _t(sd, "embedding.stem.conv.weight"), None)
     pt["feat"] = _gelu(_batchnorm_eval(sd, "embedding.stem.norm", x))
     n_orders = len(cfg["order"])
     note = (lambda name: trace.append((name, pt["feat"].clone()))) if trace is not None else (lambda name: None)

@@ -40,7 +40,7 @@ def test_binding_table_matches_header():
 def test_version_and_arch(cdll):
     from pn2_amd import _hip
     cdll.pn2_arch.restype = ctypes.c_char_p
-    assert cdll.pn2_version() == _hip.ABI_VERSION == 5
+    assert cdll.pn2_version() == _hip.ABI_VERSION == 6
     assert cdll.pn2_arch() == b"gfx950"
 
 
