@@ -28,6 +28,47 @@ def plot_voxels(points, grid, trees=16):
     return g[rng.permutation(len(g))[:points]]
 
 
+def train_line(args, model, data, N, _hip):
+    """One training step of the backbone: train-mode forward (batch-statistics BatchNorm, DropPath 0.3 spread over the blocks, the
+    poolings' random choice of serialization), loss = mean square of the output rows, backward through every stage (attention
+    and submanifold-conv backward kernels of this library, torch autograd for the dense layers), fused AdamW."""
+    model.train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, fused=True)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = model(data()).feat
+        out.square().mean().backward()
+        opt.step()
+        return out
+    for _ in range(2):
+        out = step()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.reps + 1)]
+    ev[0].record()
+    for i in range(args.reps):
+        step()
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(args.reps))[args.reps // 2]
+    groups = _hip.kernel_profile(lambda: (step(), torch.cuda.synchronize()))
+    lib = {}
+    for r in groups:
+        lib[r["name"]] = lib.get(r["name"], 0.0) + r["ms"]
+    print(json.dumps({
+        "metric": "voxels/sec, PointTransformerV3 backbone fwd+bwd+AdamW (training)", "value": N / (ms * 1e-3), "unit": "voxels/s", "n_gpus": 1,
+        "ms_per_step": ms, "dtype": args.precision, "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[3] as a training step: PTv3 backbone (reference defaults, in_channels 4, drop_path 0.3), {N} "
+                               f"voxels of a 16-tree plot on a {args.grid} m grid, one cloud; output [N, {out.shape[1]}]"},
+        "library_kernels_ms": {k: round(v, 3) for k, v in sorted(lib.items(), key=lambda kv: -kv[1])},
+        "library_kernels_ms_total": round(sum(lib.values()), 3),
+        "peak_memory_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+        "note": "the rest of the step is plain torch: Linear / LayerNorm / BatchNorm / GELU layers and their autograd, gathers, the "
+                "pooling's unique / sort / segment reductions, the optimizer",
+        "parity": "unpinned (reference module not importable here); tests/test_ptv3_train.py compares every parameter gradient with "
+                  "the float64 restatement"}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--points", type=int, default=1 << 20)
@@ -35,6 +76,7 @@ def main():
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--precision", default="f32")
     ap.add_argument("--cpu-sample", type=int, default=4096)
+    ap.add_argument("--train", action="store_true", help="forward + backward + AdamW step in train mode instead of the inference forward")
     args = ap.parse_args()
     load_pkg()
     from pn2_amd import _hip
@@ -52,6 +94,8 @@ def main():
     coord = (grid.float() * args.grid)
     feat = torch.randn(N, 4, device="cuda")
     batch = torch.zeros(N, dtype=torch.int64, device="cuda")
+    if args.train:
+        return train_line(args, model, data, N, _hip)
     with torch.no_grad():
         for _ in range(2):
             out = model(data())
