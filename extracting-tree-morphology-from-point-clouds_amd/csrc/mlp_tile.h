@@ -163,6 +163,30 @@ __device__ __forceinline__ float ld_coh(const float* p) { return __hip_atomic_lo
 // operand of v_mfma_f32_32x32x16_bf16 -- row r, eight consecutive k -- is then ONE conflict-free 16-byte read instead of eight
 // 4-byte reads and eight conversions out of the fp32 [k][outer] image (which made the bf16 mode LDS-bound).
 constexpr int kPitch16 = 48;
+// ... and for a D-layout operand (global [k][outer], outer contiguous: both operands of a weight gradient, the weights of a dgrad)
+// the image stays K-MAJOR -- [k][outer] bfloat16 rows, written with one 8-byte store per 8-byte load instead of four scattered
+// 2-byte stores (which fall on 4 of the 64 banks: 8-way conflicts) -- and the matrix-core operand comes out of it with gfx950's
+// transposing read, ds_read_b64_tr_b16 (two per operand).  Row pitch = tile + 32 values: 320 bytes at a 128-tile, i.e. four
+// consecutive k rows start 64 bytes apart modulo the 256-byte bank row -- the 4 x 16 blocks of a half-wavefront's transposed
+// read cover all 64 banks once.
+#ifndef PN2_TR_IMAGE
+#define PN2_TR_IMAGE 1
+#endif
+constexpr bool kTrImage = PN2_TR_IMAGE != 0;
+template <int TILE> constexpr int kPitchTR = 2 * (TILE + 32);
+using s16x4v = __attribute__((ext_vector_type(4))) short;
+__device__ __forceinline__ bf16x8 tr_fragment(const char* image, int pitch, int outer0, int lane) {
+    // lane (r = lane & 31, h = lane >> 5) gets [outer0 + r][k = 8 h .. 8 h + 7]: per 16-lane group a 4 (k) x 16 (outer) block,
+    // lane 4 q + p of the group addresses row k0 + q, columns 4 p .. 4 p + 3
+    const int li = lane & 15, q = li >> 2, pp = li & 3, grp = (lane >> 4) & 1, h = lane >> 5;
+    const char* a = image + (8 * h + q) * pitch + 2 * (outer0 + 16 * grp + 4 * pp);
+    using lds_ptr = __attribute__((address_space(3))) s16x4v*;
+    const s16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a));
+    const s16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(a + 4 * pitch));
+    using s16x8v = __attribute__((ext_vector_type(8))) short;
+    const s16x8v v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
 #ifndef PN2_PAIRED_STORE
 #define PN2_PAIRED_STORE 0
 #endif
@@ -281,6 +305,10 @@ struct Stager {
                 const int m = RPP * p + (tid / KT), k = 4 * (tid % KT);
                 using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
                 *(bf16x4*)(S16 + m * kPitch16 + 2 * k) = bf16x4{(__bf16)w[0], (__bf16)w[1], (__bf16)w[2], (__bf16)w[3]};
+            } else if (kTrImage && TILE == 128) {   // one k of four consecutive rows: the K-major image, one 8-byte store
+                const int k = KPP * p + (tid / OQ), m = 4 * (tid % OQ);
+                using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+                *(bf16x4*)(S16 + k * kPitchTR<TILE> + 2 * m) = bf16x4{(__bf16)w[0], (__bf16)w[1], (__bf16)w[2], (__bf16)w[3]};
             } else {          // one k of four consecutive rows
                 const int k = KPP * p + (tid / OQ), m = 4 * (tid % OQ);
 #pragma unroll
@@ -623,10 +651,14 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& g0, const TAB& st, con
             bf16x8 af[NI], bf[NI];
             const char* a16 = (const char*)As[cur] + (wm * WT + l31) * kPitch16 + 16 * half;
             const char* b16 = (const char*)Bs[cur] + (wn * WT + l31) * kPitch16 + 16 * half;
+            constexpr bool A_TR = kTrImage && !A_T && TILE == 128, B_TR = kTrImage && !B_T && TILE == 128;
+            static_assert(BK * kPitchTR<TILE> <= BK * (TILE + 4) * 4, "the K-major image fits the fp32 image's buffer");
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
-                af[i] = *(const bf16x8*)(a16 + 32 * i * kPitch16);
-                bf[i] = *(const bf16x8*)(b16 + 32 * i * kPitch16);
+                af[i] = A_TR ? tr_fragment((const char*)As[cur], kPitchTR<TILE>, wm * WT + 32 * i, lane)
+                             : *(const bf16x8*)(a16 + 32 * i * kPitch16);
+                bf[i] = B_TR ? tr_fragment((const char*)Bs[cur], kPitchTR<TILE>, wn * WT + 32 * i, lane)
+                             : *(const bf16x8*)(b16 + 32 * i * kPitch16);
             }
 #pragma unroll
             for (int i = 0; i < NI; ++i)

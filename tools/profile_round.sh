@@ -13,6 +13,8 @@ echo "bench (default flags: monolithic depth 4, f32) done"
 timeout -k 10 300 python bench.py --mode rasterized > $O/bench_rasterized.json 2>> $O/bench.err
 echo "bench rasterized done"
 timeout -k 10 300 python bench.py --dtype bf16 --no-cpu-baseline > $O/bench_bf16.json 2>> $O/bench.err
+timeout -k 10 300 python bench.py --dtype bf16 --graph --no-cpu-baseline > $O/bench_bf16_graph.json 2>> $O/bench.err
+timeout -k 10 300 python bench.py --graph --no-cpu-baseline > $O/bench_graph.json 2>> $O/bench.err
 timeout -k 10 300 python bench.py --mode rasterized --dtype bf16 --no-cpu-baseline > $O/bench_rasterized_bf16.json 2>> $O/bench.err
 timeout -k 10 300 python bench.py --trees 8 --points 65536 --no-cpu-baseline > $O/bench_cfg3_8x65536.json 2>> $O/bench.err
 timeout -k 10 300 python bench.py --depth 5 --no-cpu-baseline > $O/bench_depth5.json 2>> $O/bench.err
