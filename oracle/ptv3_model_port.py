@@ -71,8 +71,8 @@ def _block(sd, p, pt, num_heads, patch_size, order_index, parts=None):
     return pt
 
 
-def _pool(sd, p, pt, stride):
-    """SerializedPooling.forward :658-729 (reduce = "max", shuffle_orders off)."""
+def _pool(sd, p, pt, stride, reduce="max"):
+    """SerializedPooling.forward :658-729 (reduce = "max" is the constructor's default, :640; shuffle_orders off)."""
     depth = (math.ceil(stride) - 1).bit_length()
     if depth > pt["depth"]:
         depth = 0
@@ -87,7 +87,8 @@ def _pool(sd, p, pt, stride):
     for k in range(code.shape[0]):
         inverse[k, order[k]] = np.arange(code.shape[1])
     proj = _linear(sd, p + ".proj", pt["feat"])[torch.from_numpy(indices)]
-    feat = torch.stack([proj[idx_ptr[i]:idx_ptr[i + 1]].max(0).values for i in range(len(counts))])
+    seg = [proj[idx_ptr[i]:idx_ptr[i + 1]] for i in range(len(counts))]
+    feat = torch.stack([r.max(0).values if reduce == "max" else r.mean(0) for r in seg])
     coord = np.stack([pt["coord"][indices[idx_ptr[i]:idx_ptr[i + 1]]].mean(0) for i in range(len(counts))])
     batch = pt["batch"][head]
     new = {"feat": _gelu(_batchnorm_eval(sd, p + ".norm.0", feat)), "coord": coord, "grid": pt["grid"][head] >> depth, "batch": batch,
@@ -123,7 +124,7 @@ def backbone_forward(sd, cfg, feat, coord, grid_coord, batch, trace=None):
     note("embedding")
     for s in range(len(cfg["enc_depths"])):
         if s > 0:
-            pt = _pool(sd, f"enc.enc{s}.down", pt, cfg["stride"][s - 1])
+            pt = _pool(sd, f"enc.enc{s}.down", pt, cfg["stride"][s - 1], cfg.get("pool_reduce", "max"))
             note(f"enc.enc{s}.down")
         for i in range(cfg["enc_depths"][s]):
             parts = {} if trace is not None else None

@@ -9,6 +9,13 @@ for p in (HERE, os.path.dirname(HERE)):
         sys.path.insert(0, p)
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _product_package():
+    """Every test file may import the (hyphenated) product package as `pn2_amd`, whatever ran before it."""
+    import helpers
+    helpers.load_pkg()
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -136,6 +136,6 @@ def test_attention_refuses_what_is_not_built():
     with pytest.raises(NotImplementedError):
         A.SerializedAttention(32, 2, 1024, enable_flash=True)
     with pytest.raises(NotImplementedError):
-        A.patch_attention(torch.randn(32, 96, device="cuda", requires_grad=True), None, 16, 2, 0.25)
+        A.SerializedAttention(32, 2, 1024, enable_rpe=True)
     with pytest.raises(RuntimeError):
         A.patch_attention(torch.randn(32, 3 * 64, device="cuda"), None, 16, 2, 0.25)      # head width 32: not the built one

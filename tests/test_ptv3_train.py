@@ -87,16 +87,25 @@ def _small_cfg():
 
 def test_backbone_parameter_gradients_vs_float64_restatement(monkeypatch):
     """d(sum(out * R)) / d(every parameter) of the backbone (running-statistics BatchNorm, no stochastic depth: the restatement's
-    setting) against torch autograd through oracle/ptv3_model_port.py in float64."""
+    setting) against torch autograd through oracle/ptv3_model_port.py in float64.
+    The poolings reduce with "mean" here instead of the constructor's default "max": a max over a cluster is not differentiable
+    where two rows tie, and with ~360 000 (cluster, channel) maxima per stage one of them is closer than fp32 rounding in about
+    every second pass -- the forward's last-bit noise (LDS float atomics in the wide convolutions) then moves that gradient
+    element to another row, 7e-4 of the weight gradients' norm (tools/debug_ptv3_grad.py: the forward agrees to 7e-7, the
+    gradients are bimodal from pass to pass).  The max reduction is torch's segment_reduce, not a kernel of this library."""
     helpers.load_pkg()
     from oracle import ptv3_model_port as P
     from pn2_amd.PointTransformerV3.PointTransformerV3 import PointTransformerV3
     cfg = _small_cfg()
     torch.manual_seed(0)
     model = PointTransformerV3(**cfg).cuda().eval()
+    from pn2_amd.PointTransformerV3.blocks import SerializedPooling
     for m in model.modules():
         if hasattr(m, "shuffle_orders"):
             m.shuffle_orders = False
+        if isinstance(m, SerializedPooling):
+            m.reduce = "mean"
+    cfg = dict(cfg, pool_reduce="mean")
     g = torch.Generator().manual_seed(1)
     with torch.no_grad():
         for m in model.modules():
@@ -126,16 +135,15 @@ def test_backbone_parameter_gradients_vs_float64_restatement(monkeypatch):
     want = P.backbone_forward(sd64, cfg, feat, coord, grid, batch)
     assert _rel(point.feat.detach(), want.detach()) <= 2e-4
     (want * R).sum().backward()
-    worst, n = 0.0, 0
+    errs = {}
     for name, p in model.named_parameters():
         ref = sd64[name].grad
         assert ref is not None and p.grad is not None, name
-        err = float((p.grad.double().cpu() - ref).norm()) / max(float(ref.norm()), 1e-30)
-        worst = max(worst, err)
-        n += 1
-        assert err <= 1e-4, (name, err)      # measured: 2.4e-6
-    print(f"backbone gradients: {n} parameters, worst relative L2 error {worst:.2e}")
-    assert n > 150
+        errs[name] = float((p.grad.double().cpu() - ref).norm()) / max(float(ref.norm()), 1e-30)
+    bad = sorted(((e, k) for k, e in errs.items() if not e <= 1e-4), reverse=True)      # measured: 2.4e-6 at worst
+    print(f"backbone gradients: {len(errs)} parameters, worst relative L2 error {max(errs.values()):.2e}")
+    assert not bad, bad[:12]
+    assert len(errs) > 150
 
 
 def test_training_steps_with_stochastic_depth_reduce_the_loss():
