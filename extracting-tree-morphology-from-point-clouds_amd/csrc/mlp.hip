@@ -1061,8 +1061,11 @@ int launch_gemm_tv(GemmArgs& g, const Segs& S, hipStream_t s, int* nblk_out) {
                                                                                      : "gemm_wgrad_bf16")
                             : (EPI == EPI_FWD ? "gemm_fwd" : EPI == EPI_STORE ? (closing ? "gemm_dgrad_acc" : "gemm_dgrad") : "gemm_wgrad");
     const double mk = (double)g.M * g.K * (A_KIND == TR_DY ? 2 : 1), kn = (double)g.K * g.N * (B_KIND == TR_DY ? 2 : 1);
-    const double extra = (closing ? 1.0 : 0.0) + ((EPI == EPI_STORE && g.partial) ? 1.0 : 0.0);   // C read, ey read
-    const double bytes = 4.0 * (mk + kn + (double)g.M * g.N * ((EPI == EPI_SLAB ? nblk : 1) + extra));
+    // algorithmic bytes with the rows' storage type (ST: bfloat16 A / B / C / ey rows are 2 bytes per element; slabs stay fp32)
+    const double ea = (ST & 1) ? 2.0 : 4.0, eb = (ST & 2) ? 2.0 : 4.0, ec = ((ST & 4) && EPI != EPI_SLAB) ? 2.0 : 4.0, ee = (ST & 8) ? 2.0 : 4.0;
+    const double mn = (double)g.M * g.N;
+    const double bytes = ea * mk + eb * kn + ec * mn * ((EPI == EPI_SLAB ? nblk : 1) + (closing ? 1.0 : 0.0)) +
+                         ((EPI == EPI_STORE && g.partial) ? ee * mn : 0.0);   // (closing: C is read too; partial: the ey rows)
     if (closing && !DUAL)
         PN2_LAUNCH(name, bytes, 2.0 * g.M * g.N * g.K,
                    (gemm_kernel<A_T, A_KIND, B_T, B_KIND, EPI, TILE, VEC, TEAMS, BF16, EPI == EPI_STORE && !DUAL, NTT, ST>), grid,
