@@ -9,6 +9,7 @@ from functools import partial
 import torch
 import torch.nn as nn
 
+from .linear import Linear
 from .blocks import Block, Embedding, Point, PointModule, PointSequential, SerializedPooling, SerializedUnpooling
 
 
@@ -86,11 +87,11 @@ class MLP_Head(nn.Sequential):
     def __init__(self, in_channels, out_channels, norm_fn=None, num_layers=2):
         modules = []
         for _ in range(num_layers - 1):
-            modules.append(nn.Linear(in_channels, in_channels))
+            modules.append(Linear(in_channels, in_channels))
             if norm_fn:
                 modules.append(norm_fn(in_channels))
             modules.append(nn.ReLU())
-        modules.append(nn.Linear(in_channels, out_channels))
+        modules.append(Linear(in_channels, out_channels))
         super().__init__(*modules)
 
     def init_weights(self):

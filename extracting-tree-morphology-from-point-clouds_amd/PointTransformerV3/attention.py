@@ -15,6 +15,7 @@ import torch.nn as nn
 
 from .. import _hip
 from ..mlp import _PRECISION_CODE
+from .linear import Linear
 
 ATTENTION_PRECISION = "f32"          # "f32" (exact fp32 MFMA: the parity mode) or "bf16" (bfloat16 operands, fp32 softmax)
 
@@ -119,8 +120,8 @@ class SerializedAttention(nn.Module):
         self.scale = qk_scale or (channels // num_heads) ** -0.5
         self.order_index = order_index
         self.patch_size_max, self.patch_size = patch_size, 0
-        self.qkv = nn.Linear(channels, channels * 3, bias=qkv_bias)
-        self.proj = nn.Linear(channels, channels)
+        self.qkv = Linear(channels, channels * 3, bias=qkv_bias)
+        self.proj = Linear(channels, channels)
 
     @staticmethod
     def _get(point, key):

@@ -13,12 +13,14 @@ neighbour tables instead of a spconv.SparseConvTensor.
 Inference and training (the attention and the sparse convolutions have backward kernels, attention.py / cpe.py; the rest is
 torch autograd); PARITY UNPINNED against the reference, whose module cannot be imported here -- the restatement the tests use is oracle/ptv3_model_port.py."""
 import math
+import os
 from collections import OrderedDict
 
 import torch
 import torch.nn as nn
 
 from .attention import SerializedAttention
+from .linear import Linear
 from .cpe import SubMConv3d, subm_neighbors
 from .serialization.default import serialize
 
@@ -149,9 +151,9 @@ class MLP(nn.Module):
         super().__init__()
         out_channels = out_channels or in_channels
         hidden_channels = hidden_channels or in_channels
-        self.fc1 = nn.Linear(in_channels, hidden_channels)
+        self.fc1 = Linear(in_channels, hidden_channels)
         self.act = act_layer()
-        self.fc2 = nn.Linear(hidden_channels, out_channels)
+        self.fc2 = Linear(hidden_channels, out_channels)
         self.drop = nn.Dropout(drop)
 
     def forward(self, x):
@@ -186,7 +188,7 @@ class Block(PointModule):
         super().__init__()
         self.channels, self.pre_norm = channels, pre_norm
         self.cpe = PointSequential(SubMConv3d(channels, channels, kernel_size=3, bias=True, indice_key=cpe_indice_key),
-                                   nn.Linear(channels, channels), norm_layer(channels))
+                                   Linear(channels, channels), norm_layer(channels))
         self.norm1 = PointSequential(norm_layer(channels))
         self.attn = SerializedAttention(channels=channels, patch_size=patch_size, num_heads=num_heads, qkv_bias=qkv_bias,
                                         qk_scale=qk_scale, attn_drop=attn_drop, proj_drop=proj_drop, order_index=order_index,
@@ -229,7 +231,7 @@ class SerializedPooling(PointModule):
         self.stride = stride
         assert reduce in ["sum", "mean", "min", "max"]
         self.reduce, self.shuffle_orders, self.traceable = reduce, shuffle_orders, traceable
-        self.proj = nn.Linear(in_channels, out_channels)
+        self.proj = Linear(in_channels, out_channels)
         self.norm = PointSequential(norm_layer(out_channels)) if norm_layer is not None else None
         self.act = PointSequential(act_layer()) if act_layer is not None else None
 
@@ -279,8 +281,8 @@ class SerializedUnpooling(PointModule):
 
     def __init__(self, in_channels, skip_channels, out_channels, norm_layer=None, act_layer=None, traceable=False):
         super().__init__()
-        self.proj = PointSequential(nn.Linear(in_channels, out_channels))
-        self.proj_skip = PointSequential(nn.Linear(skip_channels, out_channels))
+        self.proj = PointSequential(Linear(in_channels, out_channels))
+        self.proj_skip = PointSequential(Linear(skip_channels, out_channels))
         if norm_layer is not None:
             self.proj.add(norm_layer(out_channels))
             self.proj_skip.add(norm_layer(out_channels))

@@ -735,19 +735,37 @@ __global__ __launch_bounds__(256) void slab_reduce_multi_kernel(const SlabTasks 
 constexpr int CS_ROWS = 1024;
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dz, long long ld, int rows, int C,
                                                      float* __restrict__ partial) {
+    // cw consecutive lanes walk cw consecutive channels of a row (coalesced), 256 / cw rows in parallel; the row groups are
+    // joined through LDS in fixed order.  (The first version walked one channel at a time with a row per thread: one pass over
+    // the tensor's cache lines PER CHANNEL -- fine for a 3-wide head, 1.6 ms per call on a 1 M x 96 PointTransformerV3 layer.)
     __shared__ float red[256];
     const int r0 = blockIdx.x * CS_ROWS;
     const int r1 = r0 + CS_ROWS < rows ? r0 + CS_ROWS : rows;
-    for (int c = 0; c < C; ++c) {
+    int cw = 1;
+    while (cw < C && cw < 64) cw <<= 1;
+    const int nr = 256 / cw, cx = (int)threadIdx.x % cw, ry = (int)threadIdx.x / cw;
+    for (int c0 = 0; c0 < C; c0 += cw) {
+        const int c = c0 + cx;
         float a = 0.f;
-        for (int r = r0 + threadIdx.x; r < r1; r += 256) a += dz[(long long)r * ld + c];
+        if (c < C) {
+            float a1 = 0.f, a2 = 0.f, a3 = 0.f;   // four independent loads in flight
+            int r = r0 + ry;
+            for (; r + 3 * nr < r1; r += 4 * nr) {
+                a += dz[(long long)r * ld + c];
+                a1 += dz[(long long)(r + nr) * ld + c];
+                a2 += dz[(long long)(r + 2 * nr) * ld + c];
+                a3 += dz[(long long)(r + 3 * nr) * ld + c];
+            }
+            for (; r < r1; r += nr) a += dz[(long long)r * ld + c];
+            a = (a + a1) + (a2 + a3);
+        }
         red[threadIdx.x] = a;
         __syncthreads();
-        for (int s = 128; s > 0; s >>= 1) {
-            if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        for (int sft = nr >> 1; sft > 0; sft >>= 1) {
+            if (ry < sft) red[threadIdx.x] += red[threadIdx.x + sft * cw];
             __syncthreads();
         }
-        if (threadIdx.x == 0) partial[(long long)blockIdx.x * C + c] = red[0];
+        if (ry == 0 && c < C) partial[(long long)blockIdx.x * C + c] = red[cx];
         __syncthreads();
     }
 }

@@ -675,6 +675,20 @@ class _BareConv:
         self.bias = None if conv.bias is None else conv.bias.detach()
 
 
+class _LinearAsConv:
+    """An nn.Linear seen as the 1 x 1 conv it is (weight [C_out, C_in], bias), for chain_rows."""
+
+    def __init__(self, lin):
+        self.weight, self.bias, self.out_channels = lin.weight, lin.bias, lin.out_features
+
+
+def linear_rows(rows, lin):
+    """rows [R, C_in] -> lin(rows) [R, C_out] as a one-layer chain: the forward / input-gradient GEMM kernels of this library and the
+    split-K weight gradient (deterministic slab sums) instead of the BLAS library's -- whose kernels for R ~ 10^6 rows and 32-512
+    channels run at a tenth of the memory system's pace (a PointTransformerV3 training step spends 0.2 s in them, tools/prof_ptv3_torch.py)."""
+    return chain_rows(rows, [(_LinearAsConv(lin), None, False)])
+
+
 def hoisted_conv(rows, conv):
     """rows [R, C_in] -> conv(rows) [R, C_out], the bias applied but outside the graph (interp_bn_rows gives it its gradient)."""
     return chain_rows(rows, [(_BareConv(conv), None, False)])

@@ -175,3 +175,28 @@ def test_training_steps_with_stochastic_depth_reduce_the_loss():
     with torch.no_grad():
         out = model(batch, return_loss=False)
     assert bool(torch.isfinite(out["offset_predictions"]).all())
+
+
+@pytest.mark.parametrize("rows,cin,cout", [(70000, 32, 96), (70000, 128, 32), (5000, 512, 2048), (3000, 64, 2), (1024, 36, 100)])
+def test_linear_on_library_gemms_equals_torch_linear(rows, cin, cout):
+    """PointTransformerV3/linear.py: the dense layers of the mirror run on this library's GEMM kernels (forward, input gradient,
+    split-K weight gradient, bias column sums) -- against torch.nn.functional.linear in float64."""
+    helpers.load_pkg()
+    from pn2_amd.PointTransformerV3.linear import Linear
+    torch.manual_seed(rows + cin)
+    lin = Linear(cin, cout).cuda()
+    x0 = torch.randn(rows, cin)
+    gout = torch.randn(rows, cout)
+    x64 = x0.double().requires_grad_(True)
+    w64, b64 = lin.weight.detach().cpu().double().requires_grad_(True), lin.bias.detach().cpu().double().requires_grad_(True)
+    want = torch.nn.functional.linear(x64, w64, b64)
+    want.backward(gout.double())
+    x = x0.cuda().requires_grad_(True)
+    got = lin(x)
+    assert _rel(got.detach(), want.detach()) <= 2e-6
+    got.backward(gout.cuda())
+    assert _rel(x.grad, x64.grad) <= 2e-6
+    assert _rel(lin.weight.grad, w64.grad) <= 2e-5 and _rel(lin.bias.grad, b64.grad) <= 2e-5
+    with torch.no_grad():                                     # inference path, and torch's own for what the kernels do not take
+        assert _rel(lin(x0.cuda()), want.detach()) <= 2e-6
+        assert _rel(lin(x0.cuda()[:100]), want.detach()[:100]) <= 2e-6
