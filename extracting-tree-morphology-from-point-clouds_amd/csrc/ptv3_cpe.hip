@@ -396,34 +396,43 @@ inline size_t table_slots(int N) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Training: the weight gradient  dW[o][ci][co] = sum_i X[nbr[i][o]][ci] * dY[i][co]  (offset-major like the forward's packed
-// weights).  One workgroup per (offset, 64 x 64 tile of (ci, co), row range): 32 rows per step -- the gathered X rows (absent
+// weights).  One workgroup per (offset, 64 x 64 or 128 x 128 tile of (ci, co), row range): 32 rows per step -- the gathered X rows (absent
 // neighbour: zeros) and the dY rows go to LDS as [row][channel], four wavefronts own 32 x 32 each (v_mfma_f32_32x32x2_f32, the
 // contraction runs over the rows) -- a step none of whose rows has the neighbour is skipped.  Row ranges leave slabs that a
 // second launch sums in fixed order (deterministic, like the chains' split-K weight gradients).
 // The input gradient needs no kernel of its own: nbr[i][o] = j <=> nbr[j][noff - 1 - o] = i for distinct voxels, so
 // dX = subm_conv(dY, nbr, W') with W'[o][co][ci] = W[noff - 1 - o][ci][co] (PointTransformerV3/cpe.py).
-constexpr int WGK = 32, WGT = 64, WGLD = WGT + 4;
+constexpr int WGK = 32;
 constexpr int WG_SPLIT_ROWS = 4096, WG_MAX_SPLITS = 64;
 inline int wgrad_splits(int N) {
     const int n = pn2::ceil_div(N, WG_SPLIT_ROWS);
     return n < 1 ? 1 : (n > WG_MAX_SPLITS ? WG_MAX_SPLITS : n);
 }
+// T = tile edge: 64 (four wavefronts own 32 x 32 each) for layers up to 64 wide, 128 (64 x 64 each: four accumulators) for the
+// wide ones -- a (ci, co) tile re-reads the gathered rows once per tile of the OTHER dimension, so doubling the edge halves the
+// bytes of a 256-wide layer (2 x 2 x 27 instead of 4 x 4 x 27 passes over the valid rows)
+template <int T>
 __global__ __launch_bounds__(256) void subm_wgrad_kernel(const float* __restrict__ feat, long long ldf, const int* __restrict__ nbr,
                                                          int noff, const float* __restrict__ dout, long long ldo, int N, int Cin,
                                                          int Cout, int rows_per_split, float* __restrict__ slab) {
-    __shared__ float sX[WGK * WGLD], sY[WGK * WGLD];
+    constexpr int LD = T + 4, NI = T / 64, TPR = T / 4, RPP = 256 / TPR, PASSES = WGK / RPP;
+    __shared__ float sX[WGK * LD], sY[WGK * LD];
     __shared__ int sIdx[WGK];
-    const int tco_n = (Cout + WGT - 1) / WGT;
+    const int tco_n = (Cout + T - 1) / T;
     const int o = blockIdx.x % noff, tile = blockIdx.x / noff;
-    const int ci0 = (tile / tco_n) * WGT, co0 = (tile % tco_n) * WGT;
+    const int ci0 = (tile / tco_n) * T, co0 = (tile % tco_n) * T;
     const int split = blockIdx.y;
     const int r_begin = split * rows_per_split, r_end = min(N, r_begin + rows_per_split);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     using f32x16 = __attribute__((ext_vector_type(16))) float;
-    f32x16 acc;
+    f32x16 acc[NI][NI];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     for (int r0 = r_begin; r0 < r_end; r0 += WGK) {
         int mine = -1;
         if (tid < WGK) {
@@ -433,31 +442,43 @@ __global__ __launch_bounds__(256) void subm_wgrad_kernel(const float* __restrict
         }
         if (!__syncthreads_or(mine >= 0)) continue;   // (also the barrier between the previous step's reads and this one's writes)
 #pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-            const int rr = (tid >> 4) + 16 * pass, c4 = (tid & 15) * 4;
+        for (int pass = 0; pass < PASSES; ++pass) {
+            const int rr = tid / TPR + RPP * pass, c4 = (tid % TPR) * 4;
             const int j = sIdx[rr];
             float4 x4 = make_float4(0.f, 0.f, 0.f, 0.f), y4 = x4;
             if (j >= 0) {   // (a row without the neighbour contributes nothing: its dY may stay zero too)
                 if (ci0 + c4 < Cin) x4 = *(const float4*)(feat + (long long)j * ldf + ci0 + c4);
                 if (co0 + c4 < Cout) y4 = *(const float4*)(dout + (long long)(r0 + rr) * ldo + co0 + c4);
             }
-            *(float4*)(sX + rr * WGLD + c4) = x4;
-            *(float4*)(sY + rr * WGLD + c4) = y4;
+            *(float4*)(sX + rr * LD + c4) = x4;
+            *(float4*)(sY + rr * LD + c4) = y4;
         }
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < WGK; k += 2) {
-            const float a = sX[(k + (lane >> 5)) * WGLD + 32 * wm + (lane & 31)];
-            const float b = sY[(k + (lane >> 5)) * WGLD + 32 * wn + (lane & 31)];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            float a[NI], b[NI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                a[i] = sX[(k + (lane >> 5)) * LD + (T / 2) * wm + 32 * i + (lane & 31)];
+                b[i] = sY[(k + (lane >> 5)) * LD + (T / 2) * wn + 32 * i + (lane & 31)];
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
         }
     }
     float* dst = slab + ((long long)split * noff + o) * Cin * Cout;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int ci = ci0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), co = co0 + 32 * wn + (lane & 31);
-        if (ci < Cin && co < Cout) dst[(long long)ci * Cout + co] = acc[r];
-    }
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = ci0 + (T / 2) * wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int co = co0 + (T / 2) * wn + 32 * j + (lane & 31);
+                if (ci < Cin && co < Cout) dst[(long long)ci * Cout + co] = acc[i][j][r];
+            }
 }
 __global__ __launch_bounds__(256) void subm_wgrad_reduce_kernel(const float* __restrict__ slab, int nsplit, long long mn,
                                                                 float* __restrict__ dw) {
@@ -568,9 +589,15 @@ extern "C" int pn2_ptv3_subm_wgrad_f32(const float* feat, int64_t ldf, const int
     const int rps = pn2::ceil_div(pn2::ceil_div(N, nsplit), WGK) * WGK;
     hipStream_t s = (hipStream_t)stream;
     const long long mn = (long long)noff * Cin * Cout;
-    const dim3 grid((unsigned)(noff * pn2::ceil_div(Cin, WGT) * pn2::ceil_div(Cout, WGT)), (unsigned)nsplit);
-    PN2_LAUNCH("ptv3_subm_wgrad", 4.0 * N * noff * (1.0 + Cout) + 4.0 * nsplit * mn, 2.0 * noff * N * (double)Cin * Cout, subm_wgrad_kernel,
-               grid, dim3(256), s, feat, (long long)ldf, nbr, noff, dout, (long long)ldo, N, Cin, Cout, rps, (float*)workspace);
+    const int T = (Cin > 64 && Cout > 64) ? 128 : 64;
+    const dim3 grid((unsigned)(noff * pn2::ceil_div(Cin, T) * pn2::ceil_div(Cout, T)), (unsigned)nsplit);
+    const double by = 4.0 * N * noff * (1.0 + Cout) + 4.0 * nsplit * mn, fl = 2.0 * noff * N * (double)Cin * Cout;
+    if (T == 128)
+        PN2_LAUNCH("ptv3_subm_wgrad", by, fl, (subm_wgrad_kernel<128>), grid, dim3(256), s, feat, (long long)ldf, nbr, noff, dout,
+                   (long long)ldo, N, Cin, Cout, rps, (float*)workspace);
+    else
+        PN2_LAUNCH("ptv3_subm_wgrad", by, fl, (subm_wgrad_kernel<64>), grid, dim3(256), s, feat, (long long)ldf, nbr, noff, dout,
+                   (long long)ldo, N, Cin, Cout, rps, (float*)workspace);
     long long blocks = (mn + 255) / 256;
     blocks = blocks > 4096 ? 4096 : blocks;
     PN2_LAUNCH("ptv3_subm_wgrad_reduce", 4.0 * (nsplit + 1) * mn, 0, subm_wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), s,
