@@ -6,7 +6,7 @@ branch, :466-488, as ONE launch of csrc/ptv3_attention.hip -- the K x K score ma
 The repository's configuration is the non-flash path (PointTransformerV3.py:283-286: enable_flash = enable_rpe = False,
 head width 16 in every stage); `enable_flash=True` (flash_attn's fp16 kernels) and `enable_rpe=True` raise.  Training: the
 forward then also keeps the rows' log-sum-exp and the backward is two more launches of the same file (dq; dk + dv) that rebuild
-the probabilities block by block.  The two linear layers are plain library GEMMs (torch.nn.Linear).  Parity: the reference module cannot be imported here (spconv / torch_scatter / addict / timm at
+the probabilities block by block.  The two linear layers run on the chain GEMM kernels (linear.py).  Parity: the reference module cannot be imported here (spconv / torch_scatter / addict / timm at
 module level), so the oracle (oracle/ptv3_attention_port.py) restates the source text: PARITY UNPINNED."""
 import ctypes
 

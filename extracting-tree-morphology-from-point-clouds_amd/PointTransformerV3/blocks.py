@@ -4,7 +4,7 @@
 
 What runs where: the three operators that make up the backbone's time -- the space-filling-curve codes (csrc/serialize.hip),
 the serialized patch attention (csrc/ptv3_attention.hip) and the submanifold convolutions of the stem and of every Block's
-conditional positional encoding (csrc/ptv3_cpe.hip) -- are this library's kernels; the Linear / LayerNorm / BatchNorm / GELU
+conditional positional encoding (csrc/ptv3_cpe.hip) -- are this library's kernels, and so are the dense layers' GEMMs (linear.py); the LayerNorm / BatchNorm / GELU
 layers are plain library calls (torch), and so is the index bookkeeping of the pooling (unique / sort / segment reductions: the
 reference's torch + torch_scatter calls, torch_scatter.segment_csr spelled torch.segment_reduce).  The reference's dependencies
 (spconv, torch_scatter, addict, timm) are absent here, so `Point` is a plain dict with attribute access, a voxel set carries its
