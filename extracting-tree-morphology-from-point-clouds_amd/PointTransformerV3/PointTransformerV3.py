@@ -9,7 +9,7 @@ from functools import partial
 import torch
 import torch.nn as nn
 
-from .linear import Linear
+from .linear import LayerNorm, Linear
 from .blocks import Block, Embedding, Point, PointModule, PointSequential, SerializedPooling, SerializedUnpooling
 
 
@@ -32,7 +32,7 @@ class PointTransformerV3(PointModule):
         assert self.cls_mode or self.num_stages == len(dec_depths) + 1 == len(dec_channels) + 1 == len(dec_num_head) + 1 \
             == len(dec_patch_size) + 1
         bn_layer = partial(nn.BatchNorm1d, eps=1e-3, momentum=0.01)
-        ln_layer = nn.LayerNorm
+        ln_layer = LayerNorm
         act_layer = nn.GELU
         block = partial(Block, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop, proj_drop=proj_drop,
                         norm_layer=ln_layer, act_layer=act_layer, pre_norm=pre_norm, enable_rpe=enable_rpe, enable_flash=enable_flash,

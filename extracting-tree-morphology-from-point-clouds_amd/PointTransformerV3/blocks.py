@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from .attention import SerializedAttention
-from .linear import Linear
+from .linear import LayerNorm, Linear
 from .cpe import SubMConv3d, subm_neighbors
 from .serialization.default import serialize
 
@@ -183,7 +183,7 @@ class Block(PointModule):
     """:536-623: conditional positional encoding (sparse conv + Linear + norm), serialized attention, MLP, pre- or post-norm."""
 
     def __init__(self, channels, num_heads, patch_size=48, mlp_ratio=4.0, qkv_bias=True, qk_scale=None, attn_drop=0.0,
-                 proj_drop=0.0, drop_path=0.0, norm_layer=nn.LayerNorm, act_layer=nn.GELU, pre_norm=True, order_index=0,
+                 proj_drop=0.0, drop_path=0.0, norm_layer=LayerNorm, act_layer=nn.GELU, pre_norm=True, order_index=0,
                  cpe_indice_key=None, enable_rpe=False, enable_flash=True, upcast_attention=True, upcast_softmax=True):
         super().__init__()
         self.channels, self.pre_norm = channels, pre_norm

@@ -121,6 +121,10 @@ SIGNATURES = {
     "pn2_ptv3_patch_attention_lse_f32": (_int, [_vp, _i64, _vp, _i64, _int, _int, _int, _f32, _vp, _vp, _int, _vp]),
     "pn2_ptv3_patch_attention_bwd_f32": (_int, [_vp, _i64, _vp, _i64, _int, _int, _int, _f32, _vp, _vp, _vp, _vp, _vp]),
     "pn2_ptv3_subm_wgrad_workspace_bytes": (_sz, [_int, _int, _int, _int]),
+    "pn2_layer_norm_supported": (_int, [_int]),
+    "pn2_layer_norm_fwd_f32": (_int, [_vp, _i64, _vp, _vp, _f32, _i64, _int, _vp, _i64, _vp, _vp, _vp]),
+    "pn2_layer_norm_bwd_workspace_bytes": (_sz, [_i64, _int]),
+    "pn2_layer_norm_bwd_f32": (_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _int, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
     "pn2_ptv3_subm_wgrad_f32": (_int, [_vp, _i64, _vp, _int, _vp, _i64, _int, _int, _int, _vp, _vp, _sz, _vp]),
     "pn2_prof_enable": (None, [_int]),
     "pn2_prof_collect": (_int, [ctypes.c_char_p, _sz, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong),

@@ -619,6 +619,23 @@ size_t pn2_ptv3_subm_wgrad_workspace_bytes(int N, int kernel_size, int Cin, int 
 int pn2_ptv3_subm_wgrad_f32(const float *feat, int64_t ldf, const int32_t *nbr, int kernel_size, const float *dout, int64_t ldo,
                             int N, int Cin, int Cout, float *dweight, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * LayerNorm over the channels of point rows    replaces the nn.LayerNorm `norm_layer` of every PointTransformerV3 Block,
+ *   Modules/PointTransformerV3/blocks.py:551-597, on [rows][C] fp32 rows (row strides multiples of 4, 16-byte aligned bases),
+ *   C in {32, 64, 128, 256, 512} (pn2_layer_norm_supported): C / 4 (<= 64) lanes own a row, two-pass statistics in registers.
+ * pn2_layer_norm_fwd_f32   y = (x - mean) * rstd * gamma + beta (gamma / beta NULL: 1 / 0); mean, rstd [rows] are written when
+ *   both are given (what the backward needs), both NULL at inference.
+ * pn2_layer_norm_bwd_f32   dx (every element written), dgamma / dbeta [C] (overwritten; NULL: not wanted) from dy, x and the
+ *   forward's mean / rstd; the parameter gradients are per-workgroup partials in the workspace summed in fixed order by a second
+ *   launch (deterministic).  workspace: pn2_layer_norm_bwd_workspace_bytes(rows, C). */
+int pn2_layer_norm_supported(int C);
+int pn2_layer_norm_fwd_f32(const float *x, int64_t ldx, const float *gamma, const float *beta, float eps, int64_t rows, int C,
+                           float *y, int64_t ldy, float *mean, float *rstd, void *stream);
+size_t pn2_layer_norm_bwd_workspace_bytes(int64_t rows, int C);
+int pn2_layer_norm_bwd_f32(const float *dy, int64_t lddy, const float *x, int64_t ldx, const float *mean, const float *rstd,
+                           const float *gamma, int64_t rows, int C, float *dx, int64_t lddx, float *dgamma, float *dbeta,
+                           void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -200,3 +200,32 @@ def test_linear_on_library_gemms_equals_torch_linear(rows, cin, cout):
     with torch.no_grad():                                     # inference path, and torch's own for what the kernels do not take
         assert _rel(lin(x0.cuda()), want.detach()) <= 2e-6
         assert _rel(lin(x0.cuda()[:100]), want.detach()[:100]) <= 2e-6
+
+
+@pytest.mark.parametrize("rows,C", [(70001, 32), (33333, 64), (9000, 128), (4097, 256), (1500, 512), (3, 32)])
+def test_layer_norm_kernels_equal_torch_layer_norm(rows, C):
+    """PointTransformerV3/linear.py LayerNorm on csrc/ptv3_norm.hip, forward and backward, against torch's in float64; an
+    unsupported width falls through to torch."""
+    helpers.load_pkg()
+    from pn2_amd.PointTransformerV3.linear import LayerNorm
+    torch.manual_seed(rows + C)
+    ln = LayerNorm(C).cuda()
+    with torch.no_grad():
+        ln.weight.copy_(torch.rand(C) + 0.5)
+        ln.bias.copy_(torch.randn(C) * 0.2)
+    x0 = torch.randn(rows, C) * 2.0 + 0.7
+    gout = torch.randn(rows, C)
+    x64 = x0.double().requires_grad_(True)
+    w64, b64 = ln.weight.detach().cpu().double().requires_grad_(True), ln.bias.detach().cpu().double().requires_grad_(True)
+    want = torch.nn.functional.layer_norm(x64, (C,), w64, b64, ln.eps)
+    want.backward(gout.double())
+    x = x0.cuda().requires_grad_(True)
+    got = ln(x)
+    assert _rel(got.detach(), want.detach()) <= 2e-6
+    got.backward(gout.cuda())
+    assert _rel(x.grad, x64.grad) <= 5e-6
+    assert _rel(ln.weight.grad, w64.grad) <= 2e-5 and _rel(ln.bias.grad, b64.grad) <= 2e-5
+    with torch.no_grad():
+        assert _rel(ln(x0.cuda()), want.detach()) <= 2e-6
+    odd = LayerNorm(48).cuda()
+    assert tuple(odd(torch.randn(10, 48, device="cuda")).shape) == (10, 48)
