@@ -732,7 +732,7 @@ __global__ __launch_bounds__(256) void slab_reduce_multi_kernel(const SlabTasks 
 
 // partial[blk][c] = sum over the block's rows of dz[r][c]  (bias of a layer WITHOUT BatchNorm, e.g. the last
 // conv of a head); summed in fixed order by colsum_finalize_kernel -> deterministic
-constexpr int CS_ROWS = 1024;
+constexpr int CS_ROWS = 256;   // (1024: 179 workgroups for a 183 000-row layer -- fewer than compute units; 0.43 -> 0.2 ms at 768 channels)
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ dz, long long ld, int rows, int C,
                                                      float* __restrict__ partial) {
     // cw consecutive lanes walk cw consecutive channels of a row (coalesced), 256 / cw rows in parallel; the row groups are

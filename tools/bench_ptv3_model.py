@@ -84,7 +84,9 @@ def main():
     from pn2_amd.PointTransformerV3.PointTransformerV3 import PointTransformerV3
     from pn2_amd.PointTransformerV3 import cpe
     A.ATTENTION_PRECISION = args.precision        # bf16: bfloat16 MFMA operands in the patch attention and in the submanifold
-    cpe.CONV_PRECISION = args.precision           # convolutions of the layers >= 64 wide; the torch layers stay fp32
+    cpe.CONV_PRECISION = args.precision           # convolutions of the layers >= 64 wide, and in the dense layers' GEMMs (fp32 rows)
+    from pn2_amd import mlp
+    mlp.GEMM_PRECISION = args.precision
     torch.manual_seed(0)
     model = PointTransformerV3(in_channels=4).cuda().eval()
     g = plot_voxels(args.points, args.grid)
