@@ -51,6 +51,8 @@ timeout -k 10 300 python tools/bench_ptv3_cpe.py --widths 32,64,128,256 > $O/ben
 timeout -k 10 600 python tools/bench_ptv3_model.py > $O/bench_ptv3_model.json 2>> $O/bench.err
 timeout -k 10 600 python tools/bench_ptv3_model.py --precision bf16 >> $O/bench_ptv3_model.json 2>> $O/bench.err
 timeout -k 10 600 python tools/bench_ptv3_model.py --train > $O/bench_ptv3_train.json 2>> $O/bench.err
+timeout -k 10 300 python tools/bench_ptv3_wgrad.py 2>/dev/null | grep -v amdgpu.ids > $O/bench_ptv3_wgrad.txt || true
+timeout -k 10 300 python tools/bench_linear_rows.py 2>/dev/null | grep -v amdgpu.ids > $O/bench_linear_rows.txt || true
 timeout -k 10 300 python tools/bench_chain.py --reps 50 > $O/bench_chain.txt 2>> $O/bench.err
 if [ -f extracting-tree-morphology-from-point-clouds_amd/build_diag/libpn2hip_gemm_diag.so ]; then   # tools/build_diag_gemm.sh
   timeout -k 10 200 python tools/diag_gemm.py 2>/dev/null | grep -v amdgpu.ids > $O/diag_gemm.txt || true
