@@ -2217,22 +2217,34 @@ __global__ __launch_bounds__(256) void group_dy_scatter_kernel(const float* __re
     }
 }
 
-// dwx[c * ld + d] = sum over the scatter's workgroups, fixed order
-__global__ __launch_bounds__(256) void group_wx_reduce_kernel(const float* __restrict__ wpart, int nblk, int C,
-                                                              float* __restrict__ dwx, long long ld) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= 3 * C) return;
+// dwx[c * ld + d] = sum over the scatter's workgroups, fixed order: 16 wavefronts (lane = element) take every 16th partial each,
+// four loads in flight, and are joined in order (one thread per element walking all 1024 partials was 256 dependent rounds: 77 us)
+constexpr int GWX_W = 16;
+__global__ __launch_bounds__(64 * GWX_W) void group_wx_reduce_kernel(const float* __restrict__ wpart, int nblk, int C,
+                                                                     float* __restrict__ dwx, long long ld) {
+    __shared__ float red[GWX_W][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
+    const bool ok = e < 3 * C;
     float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-    int k = 0;
-    for (; k + 4 <= nblk; k += 4) {
-        a0 += wpart[(long long)k * 3 * C + e];
-        a1 += wpart[(long long)(k + 1) * 3 * C + e];
-        a2 += wpart[(long long)(k + 2) * 3 * C + e];
-        a3 += wpart[(long long)(k + 3) * 3 * C + e];
+    if (ok) {
+        int k = w;
+        for (; k + 3 * GWX_W < nblk; k += 4 * GWX_W) {
+            a0 += wpart[(long long)k * 3 * C + e];
+            a1 += wpart[(long long)(k + GWX_W) * 3 * C + e];
+            a2 += wpart[(long long)(k + 2 * GWX_W) * 3 * C + e];
+            a3 += wpart[(long long)(k + 3 * GWX_W) * 3 * C + e];
+        }
+        for (; k < nblk; k += GWX_W) a0 += wpart[(long long)k * 3 * C + e];
     }
-    for (; k < nblk; ++k) a0 += wpart[(long long)k * 3 * C + e];
-    const int d = e / C, c = e - d * C;
-    dwx[(long long)c * ld + d] = (a0 + a1) + (a2 + a3);
+    red[w][lane] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (w == 0 && ok) {
+        float t = 0.0f;
+        for (int i = 0; i < GWX_W; ++i) t += red[i][lane];
+        const int d = e / C, c = e - d * C;
+        dwx[(long long)c * ld + d] = t;
+    }
 }
 
 bool group_bn_args_ok(const void* xyz, const void* new_xyz, const void* idx, int B, int N, int S, int K, const pn2_mlp_layer* L,
@@ -2335,7 +2347,7 @@ extern "C" int pn2_group_bn_bwd_f32(const float* dout, const float* xyz, int64_t
     PN2_LAUNCH("group_bn_bwd", (double)rows * (8.0 * C + 20.0) + 4.0 * B * N * C, 8.0 * rows * C, group_dy_scatter_kernel, dim3(nb),
                dim3(256), s, dout, (const float*)L.y, (const float*)L.stats, L.relu, xyz, (long long)sb, (long long)sn, (long long)sc,
                new_xyz, idx, groups, N, S, K, C, dgf, wpart, st);
-    PN2_LAUNCH("group_bn_wx", 12.0 * nb * C, 0, group_wx_reduce_kernel, dim3(pn2::ceil_div(3 * C, 256)), dim3(256), s,
+    PN2_LAUNCH("group_bn_wx", 12.0 * nb * C, 0, group_wx_reduce_kernel, dim3(pn2::ceil_div(3 * C, 64)), dim3(64 * GWX_W), s,
                (const float*)wpart, nb, C, dwx, (long long)lddw);
     PN2_LAUNCH_CHECK();
     return 0;
