@@ -202,7 +202,14 @@ def require_device(*tensors):
             raise RuntimeError("pn2_amd ops run on a HIP device only (no CPU fallback); got a CPU tensor")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr():
+    """The current HIP stream of the current device as an integer handle.  torch.cuda.current_stream() builds a Stream object per
+    call (8 us, 44 calls per headline step = 0.35 ms of a 3.6 ms host path); the raw accessor torch's own extensions use is ~0.3 us."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

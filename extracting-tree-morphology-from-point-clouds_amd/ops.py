@@ -60,7 +60,7 @@ def coop_ctl(device):
     dev = torch.device(device)
     if dev.index is None:
         dev = torch.device("cuda", torch.cuda.current_device())
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    key = (dev.index, _hip._raw_stream(dev.index) if _hip._raw_stream is not None else torch.cuda.current_stream(dev).cuda_stream)
     rec = _coop_ctl.get(key)
     if rec is None:
         words = torch.zeros(64, dtype=torch.int32, device=dev)

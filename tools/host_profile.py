@@ -11,6 +11,7 @@ from pn2_amd.PointNet2.PointNet2 import PointNet2
 ap = argparse.ArgumentParser()
 ap.add_argument("--dtype", default="f32")
 ap.add_argument("--top", type=int, default=45)
+ap.add_argument("--single-thread", action="store_true", help="run the autograd engine on the calling thread, so that the profile shows the backward's Python too")
 args = ap.parse_args()
 mlp.GEMM_PRECISION = args.dtype
 dev = torch.device("cuda")
@@ -35,6 +36,8 @@ t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
 print(f"host enqueue time per step {1e3 * (t1 - t0) / 20:.3f} ms; with the final sync {1e3 * (t2 - t0) / 20:.3f} ms")
+if args.single_thread:
+    torch.autograd.set_multithreading_enabled(False)
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(20):
