@@ -115,6 +115,8 @@ def test_pooled_chain_two_pass_sums(chain_rows, monkeypatch):
     (32 * 512, 67, [128, 128, 256], 32, "f32"),    # 128-tile kernels
     (32 * 512, 67, [128, 128, 256], 32, "bf16"),   # ... with bfloat16 MFMA operands (fp32 rows)
     (16 * 700, 36, [64], 16, "f32"),               # the pooled layer is the chain's first: dx straight from the rebuilt gradient
+    (32 * 1024, 8, [32, 32, 64], 32, "f32 segments"),        # three mini-batch segments (per-segment BatchNorm), 64-tile kernels
+    (32 * 512, 68, [128, 128, 256], 32, "f32 segments"),     # ... 128-tile kernels
 ])
 def test_pooled_gradient_rebuilt_while_staging_equals_dense_scatter(chain_rows, monkeypatch, rows, cin, widths, pool_k, mode):
     """TR_DYP (mlp_tile.h): the pooled layer's wgrad / dgrad rebuild the max-pool's gradient from (dout, arg-max bytes) instead
@@ -129,6 +131,11 @@ def test_pooled_gradient_rebuilt_while_staging_equals_dense_scatter(chain_rows, 
         b_.cuda().train()
     x0 = torch.randn(rows, cin, device="cuda", generator=torch.Generator("cuda").manual_seed(3))
     res = []
+    seg_off = None
+    if mode.endswith("segments"):
+        mode = mode.split()[0]
+        g = rows // pool_k
+        seg_off = [0, pool_k * (g // 5), pool_k * (g // 2 + 3), rows]
     old = M.GEMM_PRECISION
     M.GEMM_PRECISION = mode
     try:
@@ -139,7 +146,7 @@ def test_pooled_gradient_rebuilt_while_staging_equals_dense_scatter(chain_rows, 
                 for p_ in list(c_.parameters()) + list(b_.parameters()):
                     p_.grad = None
             x = x0.clone().requires_grad_(True)
-            out = chain_rows(x, layers, pool_k=pool_k)
+            out = chain_rows(x, layers, pool_k=pool_k, seg_off=seg_off)
             out.backward(torch.randn(out.shape, device="cuda", generator=torch.Generator("cuda").manual_seed(4)))
             res.append([x.grad.clone()] + [p_.grad.clone() for c_, b_, _ in layers for p_ in list(c_.parameters()) + list(b_.parameters())])
     finally:
